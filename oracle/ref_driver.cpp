@@ -1,0 +1,274 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by, or executed from the product path.
+//
+// Thin extern "C" driver around the UNMODIFIED reference sources (compiled where they
+// lie under /root/reference/src by oracle/Makefile; outputs go to oracle/_ref/).
+// Nothing from the reference is copied here: this file only *calls* reference
+// functions so the tests can pin the CPU restatement (oracle/rt_oracle.c) and
+// the HIP path against the real thing.
+//
+// How the reference's known defects are side-stepped without patching it:
+//  * src/main.cpp:86 does not compile (typo) -> main.cpp is simply not built; this
+//    driver replaces it.
+//  * RayTrace::rayTrace hard-codes the broken BVH path (src/raytrace.cpp:48) ->
+//    the driver re-states only the trivial pixel loop (src/raytrace.cpp:95-122)
+//    and calls the reference's own getRay / evaluateRayTree(..., useBVH=false) /
+//    ave / Pixel::SetClamp.  The driver is compiled with -fno-access-control so
+//    the private members are reachable.
+//  * `Pixel pix` shared across OpenMP threads (src/raytrace.cpp:91) -> the
+//    driver's loop keeps it private.
+//  * film_resolution W H stores height=W (src/parse.cpp:119) -> ref_override()
+//    sets the wanted size through the public Scene::setImage.
+//  * jitter from global rand() (src/raytrace.cpp:447-450) -> this library defines
+//    rand() itself (linked -Bsymbolic-functions, so the reference's calls bind
+//    here) and returns the shared counter-based jitter sequence
+//    rand() = hash32(seed, ((y*W+x)*spp+j)*2+k) >> 1, which the reference then
+//    divides by RAND_MAX = 2^31-1 exactly as it always does.
+#include "raytrace.h"
+
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+// ---------------------------------------------------------------- jitter
+static inline uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+static inline uint32_t jitter_hash(uint32_t seed, uint64_t counter) {
+    uint32_t hi = lowbias32((uint32_t)(counter >> 32) + seed * 0x9E3779B9U + 0x85EBCA6BU);
+    return lowbias32((uint32_t)counter ^ hi);
+}
+static thread_local uint64_t tl_counter = 0;   // ((y*W+x)*spp+j)*2, advanced by each rand()
+static thread_local uint32_t tl_seed = 1;
+
+extern "C" int rand(void) {
+    uint32_t h = jitter_hash(tl_seed, tl_counter);
+    tl_counter++;
+    return (int)(h >> 1);
+}
+
+// ---------------------------------------------------------------- state
+static Scene* g_scene = nullptr;
+static RayTrace* g_rt = nullptr;
+
+extern "C" {
+
+int ref_load_scene(const char* path) {
+    delete g_scene;
+    g_scene = new Scene();
+    if (!g_rt) g_rt = new RayTrace();
+    char buf[4096];
+    std::strncpy(buf, path, sizeof(buf) - 1);
+    buf[sizeof(buf) - 1] = 0;
+    int rc = g_scene->parseScene(buf);
+    if (rc < 0) { delete g_scene; g_scene = nullptr; }
+    return rc;
+}
+
+// any argument < 0 keeps the parsed value
+void ref_override(int w, int h, int spp, int depth) {
+    rt::Image im = g_scene->getImage();
+    if (w > 0) im.setWidth(w);
+    if (h > 0) im.setHeight(h);
+    g_scene->setImage(im);
+    if (spp > 0) g_scene->setSampleRate(spp);
+    if (depth >= 0) g_scene->setMaxDepth(depth);
+}
+
+void ref_set_proj(int ortho) { g_scene->setProjType(ortho ? ORTHO : PERSP); }
+
+// info[0..7] = width, height, spp, max_depth, nspheres, ntriangles, nlights, proj(0 ortho,1 persp)
+void ref_scene_info(int* info) {
+    info[0] = g_scene->getImage().getWidth();
+    info[1] = g_scene->getImage().getHeight();
+    info[2] = g_scene->getSampleRate();
+    info[3] = g_scene->getDepth();
+    info[4] = (int)g_scene->getSpheres().size();
+    info[5] = (int)g_scene->getTriangles().size();
+    info[6] = (int)g_scene->getLights().size();
+    info[7] = (int)g_scene->getProjType();
+}
+
+const char* ref_output_name() {
+    static std::string s;
+    s = g_scene->getImage().getFileName();
+    return s.c_str();
+}
+
+static void put3(float* dst, const Vector& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+static void put_mat(float* m, const Material& mt) {   // 14 floats, scene-file order
+    put3(m + 0, mt.getAmbient());
+    put3(m + 3, mt.getDiffuse());
+    put3(m + 6, mt.getSpecular());
+    m[9] = mt.getCosPower();
+    put3(m + 10, mt.getTransmissive());
+    m[13] = mt.getIndexRefract();
+}
+
+// Dump the parsed scene as flat arrays (caller allocates from ref_scene_info counts).
+//  spheres[n][4]  sph_mat[n][14]  tri_v[n][9]  tri_n[n][9]  tri_flag[n]  tri_mat[n][14]
+//  lights[n][12] = type, color3, pos3, dir3, a1, a2   misc[16] = cam pos3 dir3 up3 half, bg3, amb3
+void ref_dump_scene(float* spheres, float* sph_mat, float* tri_v, float* tri_n, int* tri_flag,
+                    float* tri_mat, float* lights, float* misc) {
+    std::vector<Sphere> sp = g_scene->getSpheres();
+    for (size_t i = 0; i < sp.size(); i++) {
+        put3(spheres + 4 * i, sp[i].getPosition());
+        spheres[4 * i + 3] = sp[i].getRadius();
+        put_mat(sph_mat + 14 * i, sp[i].getMaterial());
+    }
+    std::vector<Triangle> tr = g_scene->getTriangles();
+    for (size_t i = 0; i < tr.size(); i++) {
+        for (int k = 0; k < 3; k++) {
+            put3(tri_v + 9 * i + 3 * k, tr[i].getVertex(k));
+            put3(tri_n + 9 * i + 3 * k, tr[i].getNormal(k));
+        }
+        tri_flag[i] = tr[i].isNormal() ? 1 : 0;
+        put_mat(tri_mat + 14 * i, tr[i].getMaterial());
+    }
+    std::vector<Light> ls = g_scene->getLights();
+    for (size_t i = 0; i < ls.size(); i++) {
+        float* l = lights + 12 * i;
+        l[0] = (float)ls[i].getType();
+        put3(l + 1, ls[i].getColor());
+        put3(l + 4, ls[i].getPosition());
+        put3(l + 7, ls[i].getDirection());
+        l[10] = ls[i].getSpotAngle();
+        l[11] = ls[i].getMaxAngle();
+    }
+    Camera c = g_scene->getCamera();
+    put3(misc + 0, c.getPosition());
+    put3(misc + 3, c.getDirection());
+    put3(misc + 6, c.getUpDirection());
+    misc[9] = c.getHalfFOV();
+    put3(misc + 10, g_scene->getBGColor());
+    put3(misc + 13, g_scene->getAmbLight().getColor());
+}
+
+// planeDist, p1, p2 as RayTrace::rayTrace computes them (src/raytrace.cpp:76-77). out[7]
+void ref_camera_frame(double* out) {
+    int w = g_scene->getImage().getWidth(), h = g_scene->getImage().getHeight();
+    Camera c = g_scene->getCamera();
+    Vector p1, p2;
+    double pd = g_scene->getPlaneDist();
+    g_rt->getExtremePoints(c, pd, w, h, p1, p2);
+    out[0] = pd;
+    out[1] = p1.x; out[2] = p1.y; out[3] = p1.z;
+    out[4] = p2.x; out[5] = p2.y; out[6] = p2.z;
+}
+
+// Primary ray of pixel (x,y), sample j (src/raytrace.cpp:441-485). o[3], d[3]
+void ref_get_ray(int x, int y, int j, unsigned seed, float* o, float* d) {
+    int w = g_scene->getImage().getWidth(), h = g_scene->getImage().getHeight();
+    int spp = g_scene->getSampleRate();
+    Camera c = g_scene->getCamera();
+    Vector p1, p2;
+    double pd = g_scene->getPlaneDist();
+    g_rt->getExtremePoints(c, pd, w, h, p1, p2);
+    tl_seed = seed;
+    tl_counter = (((uint64_t)y * w + x) * spp + j) * 2;
+    Ray r = g_rt->getRay(x, y, w, h, p1, p2, pd, c, g_scene->getProjType(), spp > 1);
+    put3(o, r.getPosition());
+    put3(d, r.getDirection());
+}
+
+// evaluateRayTree on an arbitrary ray at an arbitrary depth, brute-force branch
+// (src/raytrace.cpp:131-151).
+void ref_trace_ray(const float* o, const float* d, int depth, float* rgb) {
+    Ray r(Vector(o[0], o[1], o[2]), Vector(d[0], d[1], d[2]));
+    Vector c = g_rt->evaluateRayTree(*g_scene, r, depth, false);
+    put3(rgb, c);
+}
+
+// RayTrace::intersect, brute-force branch (src/raytrace.cpp:154-181).
+// returns 1 on hit; out[8] = normal3, dist2, point3, mat.cosPow (material probe)
+int ref_intersect(const float* o, const float* d, double dmin, double dmax, double* out) {
+    Ray r(Vector(o[0], o[1], o[2]), Vector(d[0], d[1], d[2]));
+    Intersect* in = g_rt->intersect(r, *g_scene, dmin, dmax, false);
+    if (!in) return 0;
+    out[0] = in->normal.x; out[1] = in->normal.y; out[2] = in->normal.z;
+    out[3] = in->dist;
+    out[4] = in->p.x; out[5] = in->p.y; out[6] = in->p.z;
+    out[7] = in->m.getCosPower();
+    delete in;
+    return 1;
+}
+
+// Pixel::SetClamp(c*255.0) for one colour (src/raytrace.cpp:119, src/pixel.cpp:38-43)
+void ref_quantise(const float* rgb, unsigned char* out) {
+    Pixel p;
+    p.SetClamp(rgb[0] * 255.0, rgb[1] * 255.0, rgb[2] * 255.0);
+    out[0] = p.r; out[1] = p.g; out[2] = p.b;
+}
+
+// The pixel loop of RayTrace::rayTrace (src/raytrace.cpp:95-122) over the ROI
+// [x0,x1) x [y0,y1), brute force, with private `pix`.  rgb8 / rgbf are ROI-sized,
+// row-major top row first ((y-y0)*(x1-x0)+(x-x0)); either may be NULL.
+// Returns wall seconds.
+double ref_render(unsigned seed, int x0, int y0, int x1, int y1, int nthreads,
+                  unsigned char* rgb8, float* rgbf) {
+    Scene& scn = *g_scene;
+    ProjType proj = scn.getProjType();
+    int width = scn.getImage().getWidth(), height = scn.getImage().getHeight();
+    Camera c = scn.getCamera();
+    Vector p1, p2;
+    double planeDist = scn.getPlaneDist();
+    g_rt->getExtremePoints(c, planeDist, width, height, p1, p2);
+    int sampleNm = scn.getSampleRate();
+    bool sample = sampleNm > 1;
+    int rw = x1 - x0;
+    auto t0 = std::chrono::steady_clock::now();
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    #pragma omp parallel for collapse(2) schedule(static, 125)
+#endif
+    for (int x = x0; x < x1; x++) {
+        for (int y = y0; y < y1; y++) {
+            tl_seed = seed;
+            Vector col;
+            if (sample) {
+                Vector* color = new Vector[sampleNm];
+                for (int j = 0; j < sampleNm; j++) {
+                    tl_counter = (((uint64_t)y * width + x) * sampleNm + j) * 2;
+                    Ray trace = g_rt->getRay(x, y, width, height, p1, p2, planeDist, c, proj, sample);
+                    color[j] = g_rt->evaluateRayTree(scn, trace, 0, false);
+                }
+                col = g_rt->ave(color, sampleNm);
+                delete[] color;
+            } else {
+                Ray trace = g_rt->getRay(x, y, width, height, p1, p2, planeDist, c, proj, sample);
+                col = g_rt->evaluateRayTree(scn, trace, 0, false);
+            }
+            Pixel pix;
+            pix.SetClamp(col.x * 255.0, col.y * 255.0, col.z * 255.0);
+            size_t idx = (size_t)(y - y0) * rw + (x - x0);
+            if (rgb8) { rgb8[3 * idx] = pix.r; rgb8[3 * idx + 1] = pix.g; rgb8[3 * idx + 2] = pix.b; }
+            if (rgbf) { rgbf[3 * idx] = col.x; rgbf[3 * idx + 1] = col.y; rgbf[3 * idx + 2] = col.z; }
+        }
+    }
+    std::chrono::duration<double> el = std::chrono::steady_clock::now() - t0;
+    return el.count();
+}
+
+// Image::Write of an RGB8 top-first buffer through the reference's own Image +
+// EasyBMP (src/image.cpp:109-124) -- used to pin the product's BMP writer byte for byte.
+void ref_write_bmp(const char* path, const unsigned char* rgb8, int w, int h) {
+    Image img(w, h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            Pixel& p = img.GetPixel(x, y);
+            const unsigned char* s = rgb8 + 3 * ((size_t)y * w + x);
+            p.r = s[0]; p.g = s[1]; p.b = s[2];
+        }
+    char buf[4096];
+    std::strncpy(buf, path, sizeof(buf) - 1);
+    buf[sizeof(buf) - 1] = 0;
+    img.Write(buf);
+}
+
+}  // extern "C"
