@@ -1,0 +1,190 @@
+/* rt_api.h -- C-ABI of the MI355X-native trace loop.
+ *
+ * Drop-in replacement for ONE path of LastingLuck/Raytracer: the per-pixel trace
+ * loop behind `Image* RayTrace::rayTrace(Scene& scn)` (reference
+ * src/raytrace.h:69, src/raytrace.cpp:44-129, called from src/main.cpp:56-58).
+ * The reference has no plugin/FFI layer; this header is the seam a maintainer
+ * would bind in its place: plain pointers and sizes, no C++ types, no
+ * exceptions, no exit() inside the library.
+ *
+ * All arithmetic that decides a pixel follows the reference's brute-force
+ * branch operation for operation (float/double placement, evaluation order, no
+ * fused multiply-add), so images are reproduced bit-for-bit except where the
+ * device libm (pow, acos) rounds a double differently from glibc.
+ *
+ * Threading: calls on one rt_ctx must be serialised by the caller; different
+ * contexts (one per GPU / per process) are independent.
+ */
+#ifndef RT_API_H_
+#define RT_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,      /* bad argument / inconsistent descriptor        */
+    RT_ERR_IO = 2,           /* file could not be opened / written            */
+    RT_ERR_PARSE = 3,        /* scene file rejected (bad vertex/normal index) */
+    RT_ERR_NO_DEVICE = 4,    /* no usable HIP device: there is NO CPU fallback */
+    RT_ERR_HIP = 5,          /* a HIP runtime call failed (see rt_last_error) */
+    RT_ERR_NOMEM = 6,
+    RT_ERR_UNSUPPORTED = 7,  /* e.g. max_depth beyond the supported limit     */
+    RT_ERR_NO_SCENE = 8
+};
+
+/* Light types: numeric values of the reference's enum LightType (src/parse.h:18-23). */
+enum { RT_LIGHT_AMBIENT = 0, RT_LIGHT_DIRECTIONAL = 1, RT_LIGHT_POINT = 2, RT_LIGHT_SPOT = 3 };
+/* Projection: numeric values of the reference's enum ProjType (src/parse.h:13-16). */
+enum { RT_PROJ_ORTHO = 0, RT_PROJ_PERSP = 1 };
+/* Acceleration structure selection. */
+enum { RT_ACCEL_AUTO = 0, RT_ACCEL_BRUTE = 1, RT_ACCEL_LBVH = 2 };
+
+/* One light: the fields of the reference's class Light (src/parse.h:188-195). */
+typedef struct rt_light {
+    int32_t type;
+    float color[3];
+    float pos[3];
+    float dir[3];
+    float angle1, angle2; /* spot angles, stored raw as the parser does (src/parse.cpp:160-163) */
+} rt_light;
+
+/* Everything RayTrace::rayTrace reads from `Scene&` through its by-value getters
+ * (src/parse.h:311-327), flattened.  Borrowed for the duration of the call only.
+ * materials[i] = amb3 dif3 spec3 ns trans3 ior, the `material` directive's
+ * order (src/parse.cpp:139-149).  tri_normals holds three normals per triangle:
+ * for a flat `triangle` all three are norm(cross(v1-v0, v2-v0))
+ * (src/parse.cpp:462-469), for `normal_triangle` the file's normals
+ * (src/parse.cpp:482-491) and tri_flags[i] = 1. */
+typedef struct rt_scene_desc {
+    int32_t width, height;  /* film size (Scene::img)                   */
+    int32_t spp;            /* sample_rate; > 1 enables jitter          */
+    int32_t max_depth;      /* Scene::maxDepth                          */
+    int32_t proj;           /* RT_PROJ_*                                */
+    uint32_t seed;          /* seed of the shared jitter sequence       */
+    float cam_pos[3], cam_dir[3], cam_up[3]; /* as given, NOT normalised */
+    float cam_half_angle;   /* radians                                  */
+    float background[3];
+    float ambient[3];       /* ambient light colour                     */
+    int32_t n_spheres;
+    int32_t n_triangles;
+    int32_t n_materials;
+    int32_t n_lights;
+    const float* spheres;      /* [n_spheres][4]  cx cy cz r */
+    const int32_t* sphere_mat; /* [n_spheres]                */
+    const float* tri_verts;    /* [n_triangles][9]           */
+    const float* tri_normals;  /* [n_triangles][9]           */
+    const int32_t* tri_flags;  /* [n_triangles]              */
+    const int32_t* tri_mat;    /* [n_triangles]              */
+    const float* materials;    /* [n_materials][14]          */
+    const rt_light* lights;    /* [n_lights]                 */
+} rt_scene_desc;
+
+typedef struct rt_options {
+    int32_t device;            /* HIP device ordinal                                    */
+    int32_t accel;             /* RT_ACCEL_*; AUTO = brute force (LDS-staged) for small
+                                  scenes, LBVH above lbvh_threshold primitives          */
+    int32_t lbvh_threshold;    /* 0 = default (64)                                      */
+    int32_t batch_samples;     /* pixel-samples traced per wavefront batch, 0 = default */
+    int64_t pool_rays;         /* ray-pool capacity per batch, 0 = default (8 x batch)  */
+    void* stream;              /* hipStream_t to run on, NULL = a stream the ctx owns   */
+} rt_options;
+
+typedef struct rt_stats {
+    uint64_t rays_primary;     /* rays that reach an intersection query, by class --     */
+    uint64_t rays_secondary;   /* the reference's two `intersect` call sites             */
+    uint64_t rays_shadow;      /* (src/raytrace.cpp:139 and :536)                        */
+    uint64_t nodes_visited;    /* LBVH: inner-node box tests, closest-hit + any-hit      */
+    uint64_t prims_tested;     /* exact primitive tests                                  */
+    double ms_render;          /* device time of the whole call (HIP events)             */
+    double ms_extend;          /* closest-hit kernels                                    */
+    double ms_shadow;          /* any-hit kernels                                        */
+    double ms_shade;           /* shading + spawn + compaction kernels                   */
+    double ms_other;           /* generate, resolve, finish                              */
+    int32_t batches;
+    int32_t retries;           /* batches re-run at half size after a ray-pool overflow  */
+    int32_t accel_used;        /* RT_ACCEL_BRUTE or RT_ACCEL_LBVH                        */
+    int32_t generations;       /* deepest ray generation that held any ray, +1           */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ------------------------------------------------------------ life cycle */
+/* Replaces `RayTrace t = RayTrace();` (src/main.cpp:56, src/raytrace.cpp:33-36). */
+int rt_create(rt_ctx** out, const rt_options* opt);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_strerror(int status);
+/* Text of the last failure on this thread (HIP error string, parse message ...). */
+const char* rt_last_error(void);
+
+/* Replaces the by-value reads of `Scene&` (src/parse.h:311-327): packs the scene
+ * as SoA in HBM and, when selected, builds the LBVH that stands where the
+ * reference's BVH::make stood (src/raytrace.cpp:51-58, :652-788). */
+int rt_load_scene(rt_ctx* ctx, const rt_scene_desc* scene);
+
+/* Replaces `Image* RayTrace::rayTrace(Scene&)` (src/raytrace.cpp:44-129).
+ * rgb_out: caller-allocated width*height*3 bytes, row-major, top row first, R,G,B
+ * -- the reference's `pixels[y*width + x]` order (src/image.h:61) without the
+ * alpha byte.  rgbf_out (may be NULL): width*height*3 floats, the averaged colour
+ * before quantisation.  Both are HOST pointers. */
+int rt_render(rt_ctx* ctx, uint8_t* rgb_out, float* rgbf_out, rt_stats* stats);
+
+/* Same frame, but the result stays in device memory (d_rgb: width*height*3 bytes,
+ * device pointer).  This is what bench.py times. */
+int rt_render_device(rt_ctx* ctx, void* d_rgb, rt_stats* stats);
+
+/* --------------------------------------------------- multi-GPU tile shards */
+/* The image is cut into RT_TILE x RT_TILE tiles; tile (tx,ty) belongs to rank
+ * (tx + 3*ty) mod world.  Each rank renders only its tiles into a packed buffer
+ * (tile-major, RT_TILE*RT_TILE*3 bytes per tile, in the rank's tile order); the
+ * caller gathers the buffers (RCCL) and rank 0 assembles the frame.  The
+ * reference's counterpart is its OpenMP pixel loop (src/raytrace.cpp:92-96). */
+#define RT_TILE 32
+/* number of tiles rank owns for a width x height film */
+int rt_shard_tiles(int width, int height, int rank, int world);
+/* bytes of the packed buffer every rank must provide (same for all ranks: sized
+ * for the rank with most tiles, so an all-gather of equal slices works) */
+size_t rt_shard_bytes(int width, int height, int world);
+int rt_render_shard(rt_ctx* ctx, int rank, int world, void* d_shard, rt_stats* stats);
+/* d_all: world consecutive shard buffers of rt_shard_bytes each (device);
+ * d_rgb: width*height*3 bytes (device). */
+int rt_assemble_shards(rt_ctx* ctx, const void* d_all, int world, void* d_rgb);
+
+/* -------------------------------------------------------- query utilities */
+/* Closest-hit / any-hit queries on caller-supplied rays (host pointers), used to
+ * validate the LBVH against brute force.  o,d: [n][3].  dmax: [n] squared
+ * distances (NULL = +inf).  accel: RT_ACCEL_BRUTE or RT_ACCEL_LBVH.
+ * prim_out[n]: -1 miss, else sphere index, or n_spheres + triangle index.
+ * dist2_out[n] (may be NULL): squared distance of the hit. */
+int rt_query_rays(rt_ctx* ctx, int64_t n, const float* o, const float* d, const float* dmax,
+                  int any_hit, int accel, int32_t* prim_out, float* dist2_out);
+/* Primary ray of (x[i], y[i], sample j[i]) -- RayTrace::getRay (src/raytrace.cpp:441-485). */
+int rt_primary_rays(rt_ctx* ctx, int64_t n, const int32_t* x, const int32_t* y, const int32_t* j,
+                    float* o_out, float* d_out);
+/* value of the shared jitter sequence standing in for rand(): 0 .. 2^31-1 */
+uint32_t rt_jitter_hash(uint32_t seed, uint64_t counter);
+
+/* ----------------------------------------------- scene file and BMP output */
+/* Parser for the reference's text scene format (Scene::parseScene,
+ * src/parse.cpp:92-271).  flags: RT_PARSE_REF_COMPAT reproduces
+ * `film_resolution W H` -> W x W (src/parse.cpp:119); default honours H.
+ * out_name receives the `output_image` token (default "raytraced.bmp"). */
+enum { RT_PARSE_REF_COMPAT = 1 };
+int rt_parse_scene_file(const char* path, int flags, rt_scene_desc** out, char* out_name,
+                        size_t out_name_cap);
+void rt_free_scene(rt_scene_desc* scene);
+/* file name rule of src/main.cpp:65: name.substr(0, name.find(".bmp") + 4) */
+int rt_output_name(const char* image_name, char* out, size_t cap);
+/* 24-bit BMP exactly as Image::Write -> BMP::WriteToFile emits it
+ * (src/image.cpp:109-124, src/EasyBMP.cpp:422-598). */
+int rt_write_bmp24(const char* path, const uint8_t* rgb, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H_ */

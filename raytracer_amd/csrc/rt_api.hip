@@ -1,0 +1,607 @@
+// C-ABI of the MI355X trace loop: context, scene upload, batch scheduler.
+// See include/rt_api.h for the contract of every entry point.
+//
+// There is no CPU path: every entry point that computes needs a HIP device and
+// fails with RT_ERR_NO_DEVICE / RT_ERR_HIP otherwise.
+#include "../../include/rt_api.h"
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static_assert(RT_TILE == RT_TILE_PX, "tile size of the public header and the kernels differ");
+
+// ---------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+void rt_set_error(const std::string& s) { g_last_error = s; }
+
+extern "C" const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char* rt_strerror(int status) {
+    switch (status) {
+        case RT_OK: return "ok";
+        case RT_ERR_INVALID: return "invalid argument";
+        case RT_ERR_IO: return "file could not be opened or written";
+        case RT_ERR_PARSE: return "scene parse failed";
+        case RT_ERR_NO_DEVICE: return "no HIP device (there is no CPU fallback)";
+        case RT_ERR_HIP: return "HIP runtime error";
+        case RT_ERR_NOMEM: return "out of memory";
+        case RT_ERR_UNSUPPORTED: return "unsupported configuration";
+        case RT_ERR_NO_SCENE: return "no scene loaded";
+        default: return "unknown status";
+    }
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            rt_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+            return (e_ == hipErrorOutOfMemory) ? RT_ERR_NOMEM : RT_ERR_HIP;                   \
+        }                                                                                     \
+    } while (0)
+
+// ---------------------------------------------------------------- context
+struct rt_ctx {
+    int device = 0;
+    int num_cu = 256;
+    int max_blocks = 2048;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    rt_options opt{};
+
+    // scene
+    bool has_scene = false;
+    int accel = RT_ACCEL_BRUTE;
+    DScene S{};
+    DCamera cam{};
+    float4* d_sph = nullptr; int* d_sph_mat = nullptr;
+    float4* d_tri = nullptr; float4* d_tri_n = nullptr;
+    float4* d_mats = nullptr; DLight* d_lights = nullptr;
+    float4* d_nodes = nullptr; int* d_prim_idx = nullptr;
+
+    // ray pool
+    DPool P{};
+    DCounters* d_counters = nullptr;
+    uint64_t pool_capacity = 0;
+    uint64_t scol_capacity = 0;
+    uint64_t occl_capacity = 0;
+
+    // partition
+    int part_rank = -1, part_world = -1, part_w = -1, part_h = -1;
+    std::vector<uint32_t> tiles;
+    uint32_t* d_tiles = nullptr;
+    uint32_t* d_rowbase = nullptr; int rowbase_world = -1, rowbase_w = -1, rowbase_h = -1;
+
+    // staging
+    uint8_t* d_rgb = nullptr; float* d_rgbf = nullptr; size_t rgb_pixels = 0; size_t rgbf_pixels = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static void free_scene(rt_ctx* c) {
+    hipFree(c->d_sph); hipFree(c->d_sph_mat); hipFree(c->d_tri); hipFree(c->d_tri_n);
+    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_prim_idx);
+    c->d_sph = nullptr; c->d_sph_mat = nullptr; c->d_tri = nullptr; c->d_tri_n = nullptr;
+    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_prim_idx = nullptr;
+    c->has_scene = false;
+}
+static void free_pool(rt_ctx* c) {
+    hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.loc);
+    hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.hitlist); hipFree(c->P.occl); hipFree(c->P.scol);
+    c->P = DPool{};
+    c->pool_capacity = c->scol_capacity = c->occl_capacity = 0;
+}
+
+extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        rt_set_error("no HIP device is visible; this library has no CPU fallback");
+        return RT_ERR_NO_DEVICE;
+    }
+    rt_ctx* c = new rt_ctx();
+    if (opt) c->opt = *opt;
+    c->device = c->opt.device;
+    if (c->device < 0 || c->device >= ndev) { delete c; rt_set_error("device ordinal out of range"); return RT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->max_blocks = c->num_cu * 8;
+    if (c->opt.stream) { c->stream = (hipStream_t)c->opt.stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIP_TRY(hipMalloc(&c->d_counters, sizeof(DCounters)));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = c;
+    return RT_OK;
+}
+
+extern "C" void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_pool(c);
+    hipFree(c->d_counters); hipFree(c->d_tiles); hipFree(c->d_rowbase); hipFree(c->d_rgb); hipFree(c->d_rgbf);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---------------------------------------------------------------- camera
+// Frame constants exactly as the reference derives them on the host:
+// Scene::getPlaneDist (src/parse.cpp:275-277), RayTrace::getExtremePoints
+// (src/raytrace.cpp:635-647), and the loop-invariant head of RayTrace::getRay
+// (src/raytrace.cpp:443-445, :457-462).
+static void compute_camera(const rt_scene_desc& s, DCamera& cam) {
+    F3 pos = f3(s.cam_pos[0], s.cam_pos[1], s.cam_pos[2]);
+    F3 dir = f3(s.cam_dir[0], s.cam_dir[1], s.cam_dir[2]);
+    F3 up = f3(s.cam_up[0], s.cam_up[1], s.cam_up[2]);
+    float pdf = (float)(s.height / (2.0 * std::tan((double)s.cam_half_angle)));
+    double d = pdf, w = s.width, h = s.height;
+    F3 right = cross3(dir, up);
+    F3 p0 = pos + (dir * (float)d);
+    F3 p1 = p0 + (right * (float)(w / 2.0));
+    F3 p2 = p0 - (right * (float)(w / 2.0));
+    p1 = p1 + (up * (float)(h / 2.0));
+    p2 = p2 - (up * (float)(h / 2.0));
+    F3 rightn = norm3(cross3(dir, up));
+    F3 down = norm3(up * -1.0f);
+    F3 ptop = p2 - p1;
+    cam.pos = pos; cam.dir = dir; cam.p1 = p1;
+    cam.urv = rightn * dot3(ptop, rightn);
+    cam.blv = down * dot3(ptop, down);
+    cam.width = s.width; cam.height = s.height; cam.spp = s.spp; cam.proj = s.proj;
+    cam.seed = s.seed;
+}
+
+// ---------------------------------------------------------------- scene upload
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src, hipStream_t st) {
+    *dst = nullptr;
+    size_t n = src.size() ? src.size() : 1;
+    HIP_TRY(hipMalloc((void**)dst, n * sizeof(T)));
+    if (src.size()) HIP_TRY(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return RT_OK;
+}
+
+static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
+    if (!c || !s) return RT_ERR_INVALID;
+    if (s->width <= 0 || s->height <= 0 || s->spp <= 0 || s->n_spheres < 0 || s->n_triangles < 0 ||
+        s->n_lights < 0 || s->n_materials < 0) {
+        rt_set_error("scene descriptor: non-positive film size / sample rate or negative count");
+        return RT_ERR_INVALID;
+    }
+    if (s->max_depth + 1 > RT_MAX_GEN) { rt_set_error("max_depth beyond the supported 63"); return RT_ERR_UNSUPPORTED; }
+    if ((uint64_t)s->width > 65535u * RT_TILE || (uint64_t)s->height > 65535u * RT_TILE) return RT_ERR_UNSUPPORTED;
+    for (int i = 0; i < s->n_spheres; i++)
+        if (s->sphere_mat[i] < 0 || s->sphere_mat[i] >= s->n_materials) { rt_set_error("sphere material index out of range"); return RT_ERR_INVALID; }
+    for (int i = 0; i < s->n_triangles; i++)
+        if (s->tri_mat[i] < 0 || s->tri_mat[i] >= s->n_materials) { rt_set_error("triangle material index out of range"); return RT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    std::vector<float4> sph(s->n_spheres);
+    std::vector<int> sph_mat(s->n_spheres);
+    for (int i = 0; i < s->n_spheres; i++) {
+        const float* p = s->spheres + 4 * (size_t)i;
+        sph[i] = make_float4(p[0], p[1], p[2], p[3]);
+        sph_mat[i] = s->sphere_mat[i];
+    }
+    // triangle record: a = v0, ab = v0 - v1, ac = v0 - v2 -- the float subtractions
+    // the reference performs per test (src/raytrace.cpp:316-317), done once.
+    std::vector<float4> tri(3 * (size_t)s->n_triangles), trn(3 * (size_t)s->n_triangles);
+    for (int i = 0; i < s->n_triangles; i++) {
+        const float* v = s->tri_verts + 9 * (size_t)i;
+        const float* n = s->tri_normals + 9 * (size_t)i;
+        F3 v0 = f3(v[0], v[1], v[2]), v1 = f3(v[3], v[4], v[5]), v2 = f3(v[6], v[7], v[8]);
+        F3 ab = v0 - v1, ac = v0 - v2;
+        tri[3 * (size_t)i + 0] = make_float4(v0.x, v0.y, v0.z, ab.x);
+        tri[3 * (size_t)i + 1] = make_float4(ab.y, ab.z, ac.x, ac.y);
+        tri[3 * (size_t)i + 2] = make_float4(ac.z, u2f((uint32_t)s->tri_mat[i]), u2f(s->tri_flags[i] ? 1u : 0u), 0.0f);
+        for (int k = 0; k < 3; k++) trn[3 * (size_t)i + k] = make_float4(n[3 * k], n[3 * k + 1], n[3 * k + 2], 0.0f);
+    }
+    std::vector<float4> mats(4 * (size_t)s->n_materials);
+    for (int i = 0; i < s->n_materials; i++) {
+        const float* m = s->materials + 14 * (size_t)i;
+        mats[4 * (size_t)i + 0] = make_float4(m[0], m[1], m[2], m[9]);     // ambient, ns
+        mats[4 * (size_t)i + 1] = make_float4(m[3], m[4], m[5], m[13]);    // diffuse, ior
+        mats[4 * (size_t)i + 2] = make_float4(m[6], m[7], m[8], 0.0f);     // specular
+        mats[4 * (size_t)i + 3] = make_float4(m[10], m[11], m[12], 0.0f);  // transmissive
+    }
+    std::vector<DLight> lights(s->n_lights);
+    for (int i = 0; i < s->n_lights; i++) {
+        const rt_light& L = s->lights[i];
+        DLight& D = lights[i];
+        D.type = L.type;
+        D.cr = L.color[0]; D.cg = L.color[1]; D.cb = L.color[2];
+        D.px = L.pos[0]; D.py = L.pos[1]; D.pz = L.pos[2];
+        D.dx = L.dir[0]; D.dy = L.dir[1]; D.dz = L.dir[2];
+        D.a1 = L.angle1; D.a2 = L.angle2;
+    }
+    int rc;
+    if ((rc = upload(&c->d_sph, sph, c->stream)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_sph_mat, sph_mat, c->stream)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_tri, tri, c->stream)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_tri_n, trn, c->stream)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_mats, mats, c->stream)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_lights, lights, c->stream)) != RT_OK) return rc;
+
+    DScene& S = c->S;
+    S = DScene{};
+    S.sph = c->d_sph; S.sph_mat = c->d_sph_mat; S.tri = c->d_tri; S.tri_n = c->d_tri_n;
+    S.mats = c->d_mats; S.lights = c->d_lights;
+    S.ns = s->n_spheres; S.nt = s->n_triangles; S.nl = s->n_lights; S.max_depth = s->max_depth;
+    S.bg = f3(s->background[0], s->background[1], s->background[2]);
+    S.ambient = f3(s->ambient[0], s->ambient[1], s->ambient[2]);
+    S.n_prims = S.ns + S.nt;
+    compute_camera(*s, c->cam);
+
+    int thr = c->opt.lbvh_threshold > 0 ? c->opt.lbvh_threshold : 64;
+    int accel = c->opt.accel;
+    if (accel == RT_ACCEL_AUTO) accel = (S.n_prims > thr) ? RT_ACCEL_LBVH : RT_ACCEL_BRUTE;
+    // the LBVH is also built when brute force renders, if rt_query_rays may ask for it
+    if (S.n_prims >= 2) {
+        int root = 0;
+        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &root);
+        if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
+        S.nodes = c->d_nodes; S.prim_idx = c->d_prim_idx; S.root = root;
+    } else {
+        accel = RT_ACCEL_BRUTE;
+    }
+    c->accel = accel;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->has_scene = true;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- partition
+static inline int tile_owner(int tx, int ty, int world) { return (tx + 3 * ty) % world; }
+
+extern "C" int rt_shard_tiles(int width, int height, int rank, int world) {
+    if (width <= 0 || height <= 0 || world <= 0 || rank < 0 || rank >= world) return 0;
+    int ntx = (width + RT_TILE - 1) / RT_TILE, nty = (height + RT_TILE - 1) / RT_TILE;
+    int n = 0;
+    for (int ty = 0; ty < nty; ty++)
+        for (int tx = 0; tx < ntx; tx++)
+            if (tile_owner(tx, ty, world) == rank) n++;
+    return n;
+}
+
+extern "C" size_t rt_shard_bytes(int width, int height, int world) {
+    int m = 0;
+    for (int r = 0; r < world; r++) m = std::max(m, rt_shard_tiles(width, height, r, world));
+    return (size_t)m * RT_TILE * RT_TILE * 3;
+}
+
+static int set_partition(rt_ctx* c, int rank, int world) {
+    int w = c->cam.width, h = c->cam.height;
+    if (c->part_rank == rank && c->part_world == world && c->part_w == w && c->part_h == h) return RT_OK;
+    int ntx = (w + RT_TILE - 1) / RT_TILE, nty = (h + RT_TILE - 1) / RT_TILE;
+    c->tiles.clear();
+    for (int ty = 0; ty < nty; ty++)
+        for (int tx = 0; tx < ntx; tx++)
+            if (tile_owner(tx, ty, world) == rank) c->tiles.push_back((uint32_t)tx | ((uint32_t)ty << 16));
+    hipFree(c->d_tiles); c->d_tiles = nullptr;
+    HIP_TRY(hipMalloc(&c->d_tiles, std::max<size_t>(1, c->tiles.size()) * sizeof(uint32_t)));
+    if (!c->tiles.empty())
+        HIP_TRY(hipMemcpyAsync(c->d_tiles, c->tiles.data(), c->tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->part_rank = rank; c->part_world = world; c->part_w = w; c->part_h = h;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- pool
+static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
+    uint64_t occl = capacity * (uint64_t)std::max(1, c->S.nl);
+    if (c->pool_capacity >= capacity && c->scol_capacity >= samples && c->occl_capacity >= occl) {
+        c->P.capacity = (uint32_t)capacity;
+        return RT_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_pool(c);
+    if (capacity > 0xFFFFFFF0ull) { rt_set_error("ray pool beyond 2^32 records"); return RT_ERR_INVALID; }
+    HIP_TRY(hipMalloc(&c->P.o, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.d, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.hp, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.hn, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.loc, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.cre, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.cra, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.hitlist, capacity * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->P.occl, occl));
+    HIP_TRY(hipMalloc(&c->P.scol, samples * sizeof(float4)));
+    c->P.capacity = (uint32_t)capacity;
+    c->pool_capacity = capacity; c->scol_capacity = samples; c->occl_capacity = occl;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- batch scheduler
+struct BatchResult {
+    bool overflow = false;
+    uint64_t secondary = 0, shadow = 0, nodes = 0, prims = 0;
+    int generations = 0;
+};
+
+struct StageTimes {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // boundaries
+    std::vector<int> cat;            // category of the span that ENDS at ev[i+1]
+    hipStream_t st = nullptr;
+    void mark(int category) {
+        if (!on) return;
+        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st);
+        ev.push_back(e); cat.push_back(category);
+    }
+    void collect(double out[4]) {
+        if (!on) return;
+        for (size_t i = 1; i < ev.size(); i++) {
+            float ms = 0; hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            out[cat[i]] += ms;
+        }
+        for (auto e : ev) hipEventDestroy(e);
+        ev.clear(); cat.clear();
+    }
+};
+
+// Enqueues one batch (tiles [tile0, tile0+ntiles) of the current partition) and
+// waits for it.  All launches are asynchronous; the only host sync is the final
+// read of the counters (overflow flag + ray statistics).
+static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode, uint8_t* d_out, float* d_outf,
+                     BatchResult& res, StageTimes& tm) {
+    const DScene& S = c->S;
+    const uint32_t spp = (uint32_t)c->cam.spp;
+    const uint32_t npixels = ntiles * RT_TILE_AREA;
+    const uint64_t nsamples64 = (uint64_t)npixels * spp;
+    const uint32_t nsamples = (uint32_t)nsamples64;
+    hipStream_t st = c->stream;
+    const uint64_t cap = c->P.capacity;
+    tm.mark(3);
+    rtk_init_counters(st, c->d_counters, nsamples);
+    rtk_generate(st, c->cam, c->P, c->d_tiles, tile0, nsamples, c->max_blocks);
+    tm.mark(3);
+    uint64_t bound = nsamples;
+    for (int g = 0; g <= S.max_depth; g++) {
+        rtk_extend(st, c->accel, S, c->P, c->d_counters, g, bound, c->max_blocks);
+        tm.mark(0);
+        rtk_shadow(st, c->accel, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
+        tm.mark(1);
+        rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
+        tm.mark(2);
+        bound = std::min<uint64_t>(bound * 2, cap);
+    }
+    for (int g = S.max_depth - 1; g >= 0; g--)
+        rtk_resolve(st, S, c->P, c->d_counters, g, std::min<uint64_t>((uint64_t)nsamples << std::min(g, 20), cap), c->max_blocks);
+    rtk_finish(st, c->cam, c->P, c->d_tiles, tile0, npixels, shard_mode, d_out, d_outf, c->max_blocks);
+    tm.mark(3);
+    DCounters hc;
+    HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    res.overflow = hc.overflow != 0;
+    uint64_t used = 0;
+    for (int g = 0; g <= S.max_depth + 1 && g <= RT_MAX_GEN; g++) used += hc.gen_count[g];
+    if (used > cap) res.overflow = true;
+    if (!res.overflow) {
+        for (int g = 0; g <= S.max_depth; g++) {
+            if (g > 0) res.secondary += hc.gen_count[g];
+            res.shadow += (uint64_t)hc.hit_count[g] * (uint64_t)S.nl;
+            if (hc.gen_count[g]) res.generations = g + 1;
+        }
+        res.nodes = hc.nodes_visited; res.prims = hc.prims_tested;
+    }
+    return RT_OK;
+}
+
+static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8_t* d_out, float* d_outf,
+                           rt_stats* stats) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->has_scene) { rt_set_error("rt_load_scene has not succeeded on this context"); return RT_ERR_NO_SCENE; }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = set_partition(c, rank, world);
+    if (rc != RT_OK) return rc;
+    const uint32_t spp = (uint32_t)c->cam.spp;
+    uint64_t want_samples = c->opt.batch_samples > 0 ? (uint64_t)c->opt.batch_samples : (4ull << 20);
+    uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
+    if (per_tile > 0x7FFFFFFFull) { rt_set_error("sample_rate too large for one tile per batch"); return RT_ERR_UNSUPPORTED; }
+    uint32_t tiles_per_batch = (uint32_t)std::max<uint64_t>(1, want_samples / per_tile);
+    uint32_t total_tiles = (uint32_t)c->tiles.size();
+    tiles_per_batch = std::min(tiles_per_batch, std::max(1u, total_tiles));
+    uint64_t batch_samples = (uint64_t)tiles_per_batch * per_tile;
+    uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 6 * batch_samples;
+    capacity = std::max(capacity, batch_samples);
+    rc = ensure_pool(c, capacity, batch_samples);
+    if (rc != RT_OK) return rc;
+
+    StageTimes tm;
+    tm.st = c->stream;
+    tm.on = stats != nullptr && getenv("RT_STAGE_TIMES") != nullptr;
+    rt_stats acc{};
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // work list of (tile0, ntiles); an overflowing batch is split in two and retried
+    std::vector<std::pair<uint32_t, uint32_t>> work;
+    for (uint32_t t = total_tiles; t > 0;) {
+        uint32_t n = std::min(tiles_per_batch, t);
+        // push in reverse so the vector pops in ascending tile order
+        work.push_back({t - n, n});
+        t -= n;
+    }
+    while (!work.empty()) {
+        auto [t0, n] = work.back();
+        work.pop_back();
+        BatchResult br;
+        rc = run_batch(c, t0, n, shard_mode, d_out, d_outf, br, tm);
+        if (rc != RT_OK) return rc;
+        if (br.overflow) {
+            acc.retries++;
+            if (n == 1) {
+                // a single tile does not fit: grow the pool
+                uint64_t bigger = c->pool_capacity * 2;
+                rc = ensure_pool(c, bigger, c->scol_capacity);
+                if (rc != RT_OK) return rc;
+                work.push_back({t0, n});
+            } else {
+                uint32_t h = n / 2;
+                work.push_back({t0 + h, n - h});
+                work.push_back({t0, h});
+            }
+            continue;
+        }
+        acc.batches++;
+        acc.rays_secondary += br.secondary;
+        acc.rays_shadow += br.shadow;
+        acc.nodes_visited += br.nodes;
+        acc.prims_tested += br.prims;
+        acc.generations = std::max(acc.generations, br.generations);
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    if (stats) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        // primary rays: one per sample of every film pixel this rank owns
+        uint64_t pix = 0;
+        for (uint32_t t : c->tiles) {
+            int tx = (int)(t & 0xFFFF), ty = (int)(t >> 16);
+            int w = std::min(RT_TILE, c->cam.width - tx * RT_TILE), h = std::min(RT_TILE, c->cam.height - ty * RT_TILE);
+            pix += (uint64_t)w * h;
+        }
+        acc.rays_primary = pix * spp;
+        acc.ms_render = ms;
+        double t4[4] = {0, 0, 0, 0};
+        tm.collect(t4);
+        acc.ms_extend = t4[0]; acc.ms_shadow = t4[1]; acc.ms_shade = t4[2]; acc.ms_other = t4[3];
+        acc.accel_used = c->accel;
+        *stats = acc;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_render_device(rt_ctx* c, void* d_rgb, rt_stats* stats) {
+    if (!d_rgb) return RT_ERR_INVALID;
+    return render_internal(c, 0, 1, 0, (uint8_t*)d_rgb, nullptr, stats);
+}
+
+extern "C" int rt_render(rt_ctx* c, uint8_t* rgb_out, float* rgbf_out, rt_stats* stats) {
+    if (!c || (!rgb_out && !rgbf_out)) return RT_ERR_INVALID;
+    if (!c->has_scene) { rt_set_error("rt_load_scene has not succeeded on this context"); return RT_ERR_NO_SCENE; }
+    HIP_TRY(hipSetDevice(c->device));
+    size_t px = (size_t)c->cam.width * c->cam.height;
+    if (c->rgb_pixels < px) {
+        hipFree(c->d_rgb); c->d_rgb = nullptr;
+        HIP_TRY(hipMalloc(&c->d_rgb, px * 3));
+        c->rgb_pixels = px;
+    }
+    if (rgbf_out && c->rgbf_pixels < px) {
+        hipFree(c->d_rgbf); c->d_rgbf = nullptr;
+        HIP_TRY(hipMalloc(&c->d_rgbf, px * 3 * sizeof(float)));
+        c->rgbf_pixels = px;
+    }
+    int rc = render_internal(c, 0, 1, 0, c->d_rgb, rgbf_out ? c->d_rgbf : nullptr, stats);
+    if (rc != RT_OK) return rc;
+    if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, c->d_rgb, px * 3, hipMemcpyDeviceToHost, c->stream));
+    if (rgbf_out) HIP_TRY(hipMemcpyAsync(rgbf_out, c->d_rgbf, px * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_render_shard(rt_ctx* c, int rank, int world, void* d_shard, rt_stats* stats) {
+    if (!c || !d_shard || world <= 0 || rank < 0 || rank >= world) return RT_ERR_INVALID;
+    return render_internal(c, rank, world, 1, (uint8_t*)d_shard, nullptr, stats);
+}
+
+extern "C" int rt_assemble_shards(rt_ctx* c, const void* d_all, int world, void* d_rgb) {
+    if (!c || !d_all || !d_rgb || world <= 0) return RT_ERR_INVALID;
+    if (!c->has_scene) return RT_ERR_NO_SCENE;
+    HIP_TRY(hipSetDevice(c->device));
+    int w = c->cam.width, h = c->cam.height;
+    int ntx = (w + RT_TILE - 1) / RT_TILE, nty = (h + RT_TILE - 1) / RT_TILE;
+    if (c->rowbase_world != world || c->rowbase_w != w || c->rowbase_h != h) {
+        std::vector<uint32_t> rb((size_t)world * nty);
+        for (int r = 0; r < world; r++) {
+            uint32_t acc = 0;
+            for (int ty = 0; ty < nty; ty++) {
+                rb[(size_t)r * nty + ty] = acc;
+                int first = ((r - 3 * ty) % world + world) % world;
+                if (first < ntx) acc += (uint32_t)((ntx - first + world - 1) / world);
+            }
+        }
+        hipFree(c->d_rowbase); c->d_rowbase = nullptr;
+        HIP_TRY(hipMalloc(&c->d_rowbase, rb.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(c->d_rowbase, rb.data(), rb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->rowbase_world = world; c->rowbase_w = w; c->rowbase_h = h;
+    }
+    rtk_assemble(c->stream, (const uint8_t*)d_all, rt_shard_bytes(w, h, world), world, w, h, ntx, nty, c->d_rowbase, (uint8_t*)d_rgb);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- queries
+extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* d, const float* dmax,
+                             int any_hit, int accel, int32_t* prim_out, float* dist2_out) {
+    if (!c || n < 0 || !o || !d || !prim_out) return RT_ERR_INVALID;
+    if (!c->has_scene) return RT_ERR_NO_SCENE;
+    if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH) return RT_ERR_INVALID;
+    if (accel == RT_ACCEL_LBVH && !c->S.nodes) { rt_set_error("scene has fewer than 2 primitives: no LBVH"); return RT_ERR_UNSUPPORTED; }
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_m = nullptr, *d_d2 = nullptr; int* d_p = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() { hipFree(d_o); hipFree(d_d); hipFree(d_m); hipFree(d_d2); hipFree(d_p); };
+#define Q_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rt_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return RT_ERR_HIP; } } while (0)
+    Q_TRY(hipMalloc(&d_o, n * 3 * sizeof(float)));
+    Q_TRY(hipMalloc(&d_d, n * 3 * sizeof(float)));
+    Q_TRY(hipMalloc(&d_p, n * sizeof(int)));
+    Q_TRY(hipMalloc(&d_d2, n * sizeof(float)));
+    if (dmax) Q_TRY(hipMalloc(&d_m, n * sizeof(float)));
+    Q_TRY(hipMemcpyAsync(d_o, o, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    Q_TRY(hipMemcpyAsync(d_d, d, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (dmax) Q_TRY(hipMemcpyAsync(d_m, dmax, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rtk_query(c->stream, accel, any_hit, c->S, n, d_o, d_d, d_m, d_p, d_d2);
+    Q_TRY(hipGetLastError());
+    Q_TRY(hipMemcpyAsync(prim_out, d_p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (dist2_out) Q_TRY(hipMemcpyAsync(dist2_out, d_d2, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    Q_TRY(hipStreamSynchronize(c->stream));
+#undef Q_TRY
+    cleanup();
+    return rc;
+}
+
+extern "C" int rt_primary_rays(rt_ctx* c, int64_t n, const int32_t* x, const int32_t* y, const int32_t* j,
+                               float* o_out, float* d_out) {
+    if (!c || n < 0 || !x || !y || !j || !o_out || !d_out) return RT_ERR_INVALID;
+    if (!c->has_scene) return RT_ERR_NO_SCENE;
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int *dx = nullptr, *dy = nullptr, *dj = nullptr; float *po = nullptr, *pd = nullptr;
+    auto cleanup = [&]() { hipFree(dx); hipFree(dy); hipFree(dj); hipFree(po); hipFree(pd); };
+#define Q_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rt_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return RT_ERR_HIP; } } while (0)
+    Q_TRY(hipMalloc(&dx, n * sizeof(int))); Q_TRY(hipMalloc(&dy, n * sizeof(int))); Q_TRY(hipMalloc(&dj, n * sizeof(int)));
+    Q_TRY(hipMalloc(&po, n * 3 * sizeof(float))); Q_TRY(hipMalloc(&pd, n * 3 * sizeof(float)));
+    Q_TRY(hipMemcpyAsync(dx, x, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    Q_TRY(hipMemcpyAsync(dy, y, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    Q_TRY(hipMemcpyAsync(dj, j, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    rtk_primary_rays(c->stream, c->cam, n, dx, dy, dj, po, pd);
+    Q_TRY(hipGetLastError());
+    Q_TRY(hipMemcpyAsync(o_out, po, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    Q_TRY(hipMemcpyAsync(d_out, pd, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    Q_TRY(hipStreamSynchronize(c->stream));
+#undef Q_TRY
+    cleanup();
+    return RT_OK;
+}
+
+extern "C" uint32_t rt_jitter_hash(uint32_t seed, uint64_t counter) { return rt_jitter(seed, counter); }

@@ -1,0 +1,116 @@
+// Device-side records and the reference-exact arithmetic of the trace loop.
+//
+// Arithmetic contract (reference src/parse.h:25-75, src/parse.cpp:301-396): a
+// vector is three floats; vector/vector and vector/scalar operators work in
+// float, a double scalar is narrowed to float at the call; dot / cross /
+// magnitudeSq / lengthSq are float sums evaluated left to right; magnitude() is
+// (float)sqrt((double)sumsq) -- identical to a correctly rounded sqrtf; norm()
+// is three float divisions.  The translation unit is compiled with
+// -ffp-contract=off so no product and sum is ever fused; the only fused
+// operations are the explicit __builtin_fmaf calls of the LBVH box test, which
+// is conservative and never decides a hit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_MAX_GEN 64          // ray generations held per batch (max_depth + 1 <= RT_MAX_GEN)
+#define RT_BLOCK 256
+#define RT_TILE_PX 32          // must equal RT_TILE of the public header
+#define RT_TILE_AREA (RT_TILE_PX * RT_TILE_PX)
+
+struct F3 {
+    float x, y, z;
+};
+__host__ __device__ inline F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__host__ __device__ inline F3 f3(const float4& v) { return f3(v.x, v.y, v.z); }
+__host__ __device__ inline F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ inline F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ inline F3 operator*(F3 a, float c) { return f3(a.x * c, a.y * c, a.z * c); }
+__host__ __device__ inline F3 operator/(F3 a, float c) { return f3(a.x / c, a.y / c, a.z / c); }
+__host__ __device__ inline float dot3(F3 u, F3 v) { return (u.x * v.x) + (u.y * v.y) + (u.z * v.z); }
+__host__ __device__ inline F3 cross3(F3 u, F3 v) {
+    return f3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+__host__ __device__ inline float magsq3(F3 a) { return (a.x * a.x) + (a.y * a.y) + (a.z * a.z); }
+__host__ __device__ inline float mag3(F3 a) { return __builtin_sqrtf(magsq3(a)); }
+__host__ __device__ inline F3 norm3(F3 a) { float m = mag3(a); return f3(a.x / m, a.y / m, a.z / m); }
+__host__ __device__ inline F3 neg3(F3 a) { return f3(-a.x, -a.y, -a.z); }   // == a * -1.0f exactly
+
+// ---------------------------------------------------------------- scene (SoA in HBM)
+struct DLight {
+    int type;
+    float cr, cg, cb;
+    float px, py, pz;
+    float dx, dy, dz;
+    float a1, a2;
+};
+
+// Frame constants: computed once per frame on the host exactly as the reference
+// does (Scene::getPlaneDist src/parse.cpp:275-277, RayTrace::getExtremePoints
+// src/raytrace.cpp:635-647, the loop-invariant part of getRay :443-445,:457-462).
+struct DCamera {
+    F3 pos, dir;      // camera position, (un-normalised) direction
+    F3 p1;            // top-left corner of the view plane
+    F3 urv, blv;      // right^ * dot(p2-p1, right^),  down^ * dot(p2-p1, down^)
+    int width, height, spp, proj;
+    uint32_t seed;
+};
+
+struct DScene {
+    const float4* sph;       // [ns]  cx cy cz r
+    const int* sph_mat;      // [ns]
+    const float4* tri;       // [nt][3]  (a.xyz, ab.x) (ab.yz, ac.xy) (ac.z, mat, flag, -)
+    const float4* tri_n;     // [nt][3]  n0 n1 n2 (w unused)
+    const float4* mats;      // [nm][4]  (amb, ns) (dif, ior) (spec, -) (trans, -)
+    const DLight* lights;    // [nl]
+    int ns, nt, nl, max_depth;
+    F3 bg, ambient;
+    // LBVH (valid when nodes != nullptr)
+    const float4* nodes;     // [n_internal][4], see rt_lbvh.hip
+    const int* prim_idx;     // [ns+nt] sorted primitive ids (sphere i, or ns + triangle i)
+    int root;                // root reference
+    int n_prims;
+};
+
+// ---------------------------------------------------------------- per-batch ray pool
+// One record per traced ray, all generations of a batch kept until the bottom-up
+// colour resolve.  SoA, 16-byte elements so every access is a coalesced dwordx4.
+struct DPool {
+    float4* o;        // origin xyz, w = parent code (bits): gen 0 -> sample index; else parent ray index
+    float4* d;        // direction xyz, w = child slot (0 reflection, 1 refraction)
+    float4* hp;       // hit point xyz, w = primitive id (bits)            [valid for hit rays]
+    float4* hn;       // shading normal xyz, w = material id (bits)
+    float4* loc;      // local colour rgb, w = pending code (bits): 0 = delivered,
+                      //   else (mat << 2 | refl | refr<<1) + 4  (children still to be added)
+    float4* cre;      // colour returned by the reflection child
+    float4* cra;      // colour returned by the refraction child
+    uint32_t* hitlist;     // per generation: compacted indices of rays that hit
+    uint8_t* occl;         // per generation: [hit slot * nl + light] 1 = in shadow
+    float4* scol;          // per sample colour of the batch
+    uint32_t capacity;     // rays
+};
+
+struct DCounters {
+    uint32_t gen_count[RT_MAX_GEN + 1];   // rays per generation (appended by the shade kernel of g-1)
+    uint32_t hit_count[RT_MAX_GEN + 1];   // hits per generation
+    uint32_t overflow;                    // set when a spawn did not fit the pool
+    uint32_t pad;
+    unsigned long long nodes_visited;
+    unsigned long long prims_tested;
+};
+
+// ---------------------------------------------------------------- jitter
+__host__ __device__ inline uint32_t rt_lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+// Stand-in for rand() (reference src/raytrace.cpp:448-449): a value in 0 .. 2^31-1
+// that depends only on (seed, ((y*W+x)*spp+j)*2+k), so every device, the oracle
+// and the reference draw the same jitter for the same sample.
+__host__ __device__ inline uint32_t rt_jitter(uint32_t seed, uint64_t counter) {
+    uint32_t hi = rt_lowbias32((uint32_t)(counter >> 32) + seed * 0x9E3779B9U + 0x85EBCA6BU);
+    return rt_lowbias32((uint32_t)counter ^ hi) >> 1;
+}

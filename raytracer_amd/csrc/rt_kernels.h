@@ -1,0 +1,32 @@
+// Host-callable launchers of the wavefront kernels (rt_kernels.hip) and of the
+// LBVH builder (rt_lbvh.hip).  `bound` is an upper bound on the work items, used
+// only to size the persistent grid; the kernels read the true counts on device.
+#pragma once
+
+#include "rt_device.h"
+
+void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples);
+void rtk_generate(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles,
+                  uint32_t tile0, uint32_t nsamples, int max_blocks);
+void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
+                uint64_t bound, int max_blocks);
+void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
+                uint64_t bound, int max_blocks);
+void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
+               int max_blocks);
+void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
+                 int max_blocks);
+void rtk_finish(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles, uint32_t tile0,
+                uint32_t npixels, int shard_mode, uint8_t* out, float* outf, int max_blocks);
+void rtk_assemble(hipStream_t st, const uint8_t* all, size_t shard_bytes, int world, int width, int height,
+                  int ntx, int nty, const uint32_t* rowbase, uint8_t* out);
+void rtk_query(hipStream_t st, int accel, int any_hit, const DScene& S, int64_t n, const float* o,
+               const float* d, const float* dmax, int* prim_out, float* d2_out);
+void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* x, const int* y,
+                      const int* j, float* o_out, float* d_out);
+
+// LBVH over spheres + triangles (Morton codes -> radix sort -> Karras hierarchy ->
+// bottom-up refit).  Allocates *nodes ([n_prims-1][4] float4) and *prim_idx
+// ([n_prims]) with hipMalloc; returns a hipError_t as int.  n_prims >= 2.
+int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes,
+              int** prim_idx, int* root);

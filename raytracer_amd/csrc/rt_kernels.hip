@@ -1,0 +1,627 @@
+// Wavefront pipeline of the trace loop for gfx950 (MI355X).
+//
+//   generate -> [ extend -> shadow -> shade/spawn ] per ray generation -> resolve -> finish
+//
+// The reference recursion (evaluateRayTree -> getColor -> evaluateRayTree,
+// src/raytrace.cpp:131-151, :488-632) is unrolled generation by generation: all
+// rays of recursion depth g form one contiguous slice of a ray pool; the shade
+// kernel of depth g appends the reflection / refraction rays of depth g+1 with
+// wave64 ballot + prefix-count compaction (one atomic per wave).  Colours flow
+// back bottom-up: a ray adds spec*child and trans*child to its local colour in
+// the reference's order (:594-596, :625-627) and hands the sum to its parent's
+// slot, so every float operation of the recursion happens exactly once and in
+// the same order -- the image does not depend on batch size, queue order or
+// the number of GPUs.
+//
+// No kernel needs a host round-trip for its size: every launch is a fixed
+// persistent grid that reads the generation's ray count from device memory and
+// strides over it, so a whole batch is enqueued asynchronously.
+#include "rt_trace.h"
+#include "rt_kernels.h"
+
+// ---------------------------------------------------------------- small helpers
+__device__ inline uint32_t gen_start(const DCounters* __restrict__ c, int g) {
+    uint32_t s = 0;
+    for (int i = 0; i < g; i++) s += c->gen_count[i];
+    return s;
+}
+__device__ inline uint32_t gen_size(const DCounters* __restrict__ c, int g, uint32_t start,
+                                    uint32_t capacity) {
+    uint32_t n = c->gen_count[g];
+    if (start >= capacity) return 0;
+    uint32_t room = capacity - start;
+    return n < room ? n : room;
+}
+
+// wave64 compaction: every lane of the wave must call this (inactive lanes with
+// want = 0).  Returns this lane's offset inside the wave's allocation and the
+// allocation base obtained with ONE atomic per wave.
+__device__ inline uint32_t wave_alloc(uint32_t* counter, uint32_t want, uint32_t& base) {
+    // prefix sum of `want` (0, 1 or 2) over the wave via two ballots
+    unsigned long long m1 = __ballot(want >= 1);
+    unsigned long long m2 = __ballot(want >= 2);
+    uint32_t lane_lo = __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0);
+    uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), lane_lo);
+    uint32_t lane_lo2 = __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0);
+    off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), lane_lo2);
+    uint32_t total = (uint32_t)(__popcll(m1) + __popcll(m2));
+    uint32_t b = 0;
+    if (total) {
+        if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, total);
+        b = __builtin_amdgcn_readfirstlane(b);
+    }
+    base = b;
+    return off;
+}
+
+__device__ inline void deliver(const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c) {
+    float4 v = make_float4(c.x, c.y, c.z, 0.0f);
+    if (g == 0) P.scol[parent] = v;
+    else if (slot == 0) P.cre[parent] = v;
+    else P.cra[parent] = v;
+}
+
+// ---------------------------------------------------------------- brute force (LDS staged)
+// Spheres, then triangles, in index order with a strict `<`, which reproduces
+// the reference's tie rules: lowest index wins inside a list (:250, :361) and a
+// triangle replaces a sphere only when strictly closer (:172).  Primitives are
+// staged through LDS in chunks so scenes of any size stream once per block, not
+// once per ray.  All threads of the block must call (barriers inside).
+#define BRUTE_CHUNK 768   // float4 slots: 768 spheres or 256 triangles per chunk (12 KB)
+
+template <bool ANY>
+__device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
+                                   int& best, float& best_d2, unsigned long long& tested) {
+    double dd = (double)dot3(d, d);
+    best = -1;
+    best_d2 = dmax;
+    bool done = !active;
+    for (int base = 0; base < S.ns; base += BRUTE_CHUNK) {
+        int n = min(BRUTE_CHUNK, S.ns - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = S.sph[base + i];
+        __syncthreads();
+        if (!done) {
+            for (int i = 0; i < n; i++) {
+                float d2, tf;
+                if (sphere_test(o, d, dd, lds[i], dmax, d2, tf)) {
+                    if (best < 0 || d2 < best_d2) { best = base + i; best_d2 = d2; }
+                    if (ANY) { done = true; break; }
+                }
+            }
+            tested += n;
+        }
+    }
+    for (int base = 0; base < S.nt; base += BRUTE_CHUNK / 3) {
+        int n = min(BRUTE_CHUNK / 3, S.nt - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) lds[i] = S.tri[3 * (size_t)base + i];
+        __syncthreads();
+        if (!done) {
+            for (int i = 0; i < n; i++) {
+                F3 a, ab, ac;
+                tri_load(lds + 3 * i, a, ab, ac);
+                TriHit h;
+                if (tri_test(o, d, a, ab, ac, dmax, h)) {
+                    if (best < 0 || h.d2 < best_d2) { best = S.ns + base + i; best_d2 = h.d2; }
+                    if (ANY) { done = true; break; }
+                }
+            }
+            tested += n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LBVH traversal
+// Node i = 4 float4: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (ref0, ref1, -, -).
+// ref >= 0: inner node; ref < 0: leaf holding sorted primitive ~ref.  Boxes are
+// padded at build time and the slab test is widened, so a primitive the exact
+// test would accept is never culled; the exact tests and the
+// (distance, primitive id) lexicographic minimum then give the brute-force answer.
+__device__ inline float slab_near(float lo, float hi, float o, float inv, float& tfar) {
+    float t0 = (lo - o) * inv, t1 = (hi - o) * inv;
+    tfar = fmaxf(t0, t1);
+    return fminf(t0, t1);
+}
+__device__ inline bool box_hit(F3 lo, F3 hi, F3 o, F3 inv, float tmax, float& tnear) {
+    float fx, fy, fz;
+    float nx = slab_near(lo.x, hi.x, o.x, inv.x, fx);
+    float ny = slab_near(lo.y, hi.y, o.y, inv.y, fy);
+    float nz = slab_near(lo.z, hi.z, o.z, inv.z, fz);
+    // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a slab of
+    // a zero direction component), which keeps the test conservative.
+    float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    float tf = fminf(fminf(fx, fy), fz);
+    tnear = tn;
+    return tn <= tf * 1.0000005f && tn <= tmax;
+}
+
+#define LBVH_STACK 64
+
+template <bool ANY>
+__device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
+                                  float& best_d2, unsigned long long& nodes, unsigned long long& tested) {
+    best = -1;
+    best_d2 = dmax;
+    if (!active) return;
+    double dd = (double)dot3(d, d);
+    float ddf = dot3(d, d);
+    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // ray-parameter bound equivalent to the squared-distance bound, widened
+    float tmax = (dmax < __builtin_inff()) ? __builtin_sqrtf(dmax / ddf) * 1.00001f : __builtin_inff();
+    int stack[LBVH_STACK];
+    int sp = 0;
+    int cur = S.root;
+    while (true) {
+        if (cur >= 0) {
+            const float4* nd = S.nodes + 4 * (size_t)cur;
+            float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            nodes++;
+            float tn0, tn1;
+            bool h0 = box_hit(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), o, inv, tmax, tn0);
+            bool h1 = box_hit(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), o, inv, tmax, tn1);
+            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                if (sp < LBVH_STACK) stack[sp++] = farc;
+                cur = nearc;
+                continue;
+            } else if (h0) { cur = c0; continue; }
+            else if (h1) { cur = c1; continue; }
+        } else {
+            int prim = S.prim_idx[~cur];
+            tested++;
+            bool hit = false;
+            float d2 = 0;
+            if (prim < S.ns) {
+                float tf;
+                hit = sphere_test(o, d, dd, S.sph[prim], dmax, d2, tf);
+            } else {
+                F3 a, ab, ac;
+                tri_load(S.tri + 3 * (size_t)(prim - S.ns), a, ab, ac);
+                TriHit h;
+                hit = tri_test(o, d, a, ab, ac, dmax, h);
+                d2 = h.d2;
+            }
+            if (hit) {
+                if (ANY) { best = prim; best_d2 = d2; return; }
+                if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
+                    best = prim;
+                    best_d2 = d2;
+                    tmax = __builtin_sqrtf(d2 / ddf) * 1.00001f;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+
+template <int ACCEL, bool ANY>
+__device__ inline void trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
+                             int& best, float& best_d2, unsigned long long& nodes,
+                             unsigned long long& tested) {
+    if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, tested);
+    else lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, nodes, tested);
+}
+
+__device__ inline void flush_stats(DCounters* C, unsigned long long nodes, unsigned long long tested) {
+    for (int off = 32; off > 0; off >>= 1) {
+        nodes += __shfl_down(nodes, off);
+        tested += __shfl_down(tested, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nodes) atomicAdd(&C->nodes_visited, nodes);
+        if (tested) atomicAdd(&C->prims_tested, tested);
+    }
+}
+
+// ---------------------------------------------------------------- generate
+// Pixel of local pixel index lp: tiles of RT_TILE_PX^2 pixels, 8x8 sub-blocks inside
+// a tile so that the 64 lanes of a wave cover a compact screen region.
+__device__ inline void pixel_of(const uint32_t* __restrict__ tiles, uint32_t tile0, uint32_t lp,
+                                int& x, int& y, int& px, int& py, uint32_t& tile) {
+    tile = tile0 + (lp >> 10);
+    uint32_t pin = lp & 1023u;
+    uint32_t blk = pin >> 6, w = pin & 63u;
+    px = (int)((blk & 3u) * 8u + (w & 7u));
+    py = (int)((blk >> 2) * 8u + (w >> 3));
+    uint32_t t = tiles[tile];
+    x = (int)(t & 0xFFFFu) * RT_TILE_PX + px;
+    y = (int)(t >> 16) * RT_TILE_PX + py;
+}
+
+// RayTrace::getRay (src/raytrace.cpp:441-485) for one sample.
+__device__ inline void primary_ray(const DCamera& cam, int x, int y, int j, F3& o, F3& d) {
+    double r1, r2;
+    if (cam.spp > 1) {
+        unsigned long long c = (((unsigned long long)y * (unsigned long long)cam.width +
+                                 (unsigned long long)x) * (unsigned long long)cam.spp +
+                                (unsigned long long)j) * 2ull;
+        r1 = (double)(int)rt_jitter(cam.seed, c) / 2147483647;
+        r2 = (double)(int)rt_jitter(cam.seed, c + 1) / 2147483647;
+    } else {
+        r1 = r2 = .5;
+    }
+    int w = cam.width, h = cam.height;
+    F3 ur = cam.urv * (float)((double)x / w + (r1 / w));
+    F3 bl = cam.blv * (float)((double)y / h + (r2 / h));
+    F3 p = (ur + bl) + cam.p1;
+    if (cam.proj == 1) { o = cam.pos; d = norm3(p); }
+    else { o = p; d = cam.dir; }
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, DPool P, const uint32_t* tiles,
+                                                       uint32_t tile0, uint32_t nsamples) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nsamples; s += gridDim.x * blockDim.x) {
+        uint32_t lp = s / (uint32_t)cam.spp;
+        int j = (int)(s - lp * (uint32_t)cam.spp);
+        int x, y, px, py; uint32_t tile;
+        pixel_of(tiles, tile0, lp, x, y, px, py, tile);
+        bool valid = x < cam.width && y < cam.height;
+        F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
+        if (valid) primary_ray(cam, x, y, j, o, d);
+        P.o[s] = make_float4(o.x, o.y, o.z, bitsf(valid ? s : 0xFFFFFFFFu));
+        P.d[s] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+}
+
+__global__ void k_primary_rays(DCamera cam, int64_t n, const int* x, const int* y, const int* j,
+                               float* o_out, float* d_out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 o, d;
+    primary_ray(cam, x[i], y[i], j[i], o, d);
+    o_out[3 * i] = o.x; o_out[3 * i + 1] = o.y; o_out[3 * i + 2] = o.z;
+    d_out[3 * i] = d.x; d_out[3 * i + 1] = d.y; d_out[3 * i + 2] = d.z;
+}
+
+__global__ void k_init_counters(DCounters* C, uint32_t nsamples) {
+    int i = threadIdx.x;
+    if (i <= RT_MAX_GEN) { C->gen_count[i] = (i == 0) ? nsamples : 0; C->hit_count[i] = 0; }
+    if (i == 0) { C->overflow = 0; C->pad = 0; C->nodes_visited = 0; C->prims_tested = 0; }
+}
+
+// ---------------------------------------------------------------- extend (closest hit)
+// evaluateRayTree's intersect + miss branch (src/raytrace.cpp:139-150): a miss
+// returns the background to the parent at once; a hit is recorded and its ray
+// index appended to the generation's compacted hit list.
+template <int ACCEL>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounters* C, int g) {
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
+    const uint32_t start = gen_start(C, g);
+    const uint32_t count = gen_size(C, g, start, P.capacity);
+    unsigned long long nodes = 0, tested = 0;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+        uint32_t i = base + threadIdx.x;
+        bool inrange = i < count;
+        uint32_t r = start + (inrange ? i : 0);
+        float4 qo = P.o[r], qd = P.d[r];
+        uint32_t parent = fbits(qo.w);
+        // generation-0 slots of pixels outside the film carry no ray
+        bool active = inrange && !(g == 0 && parent == 0xFFFFFFFFu);
+        F3 o = f3(qo), d = f3(qd);
+        int best; float best_d2;
+        trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, nodes, tested);
+        bool hit = active && best >= 0;
+        if (hit) {
+            F3 point, normal; int mat;
+            make_hit(S, o, d, (double)dot3(d, d), best, __builtin_inff(), point, normal, mat);
+            P.hp[r] = make_float4(point.x, point.y, point.z, bitsf((uint32_t)best));
+            P.hn[r] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat));
+        } else if (inrange) {
+            if (active) deliver(P, g, parent, fbits(qd.w), S.bg);
+            P.loc[r] = make_float4(0, 0, 0, 0);   // nothing pending for the resolve pass
+        }
+        uint32_t wbase;
+        uint32_t off = wave_alloc(&C->hit_count[g], hit ? 1u : 0u, wbase);
+        if (hit) P.hitlist[start + wbase + off] = r;
+    }
+    flush_stats(C, nodes, tested);
+}
+
+// ---------------------------------------------------------------- shadow (any hit)
+// The shadow query of getColor (src/raytrace.cpp:523-539) for every
+// (hit, light) pair of the generation: one work item per pair.
+template <int ACCEL>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounters* C, int g) {
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
+    const uint32_t start = gen_start(C, g);
+    const uint32_t nh = C->hit_count[g];
+    const uint64_t items = (uint64_t)nh * (uint64_t)S.nl;
+    unsigned long long nodes = 0, tested = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items;
+         base += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = base + threadIdx.x;
+        bool active = k < items;
+        uint32_t h = active ? (uint32_t)(k / (uint32_t)S.nl) : 0;
+        int j = active ? (int)(k - (uint64_t)h * (uint32_t)S.nl) : 0;
+        uint32_t r = P.hitlist[start + h];
+        F3 point = f3(P.hp[r]);
+        F3 I; float dist2;
+        light_dir(S.lights[j], point, I, dist2);
+        int best; float best_d2;
+        trace<ACCEL, true>(S, lds, active, point, I, dist2, best, best_d2, nodes, tested);
+        if (active) P.occl[k] = (best >= 0) ? 1 : 0;
+    }
+    flush_stats(C, nodes, tested);
+}
+
+// ---------------------------------------------------------------- shade + spawn
+// getColor (src/raytrace.cpp:488-632) without the recursion: local illumination
+// with the shadow results, then the reflection / refraction rays of the next
+// generation are appended to the pool (or, past max_depth, the background is
+// added directly as evaluateRayTree :132-135 returns it without tracing).
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters* C, int g) {
+    const uint32_t start = gen_start(C, g);
+    const uint32_t nh = C->hit_count[g];
+    const uint32_t next_start = start + C->gen_count[g];
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nh; base += gridDim.x * blockDim.x) {
+        uint32_t h = base + threadIdx.x;
+        bool active = h < nh;
+        uint32_t want = 0;
+        uint32_t r = 0;
+        F3 point = f3(0, 0, 0), rfd = f3(0, 0, 0), rad = f3(0, 0, 0);
+        bool refl = false, refr = false;
+        if (active) {
+            r = P.hitlist[start + h];
+            float4 qd = P.d[r], qp = P.hp[r], qn = P.hn[r];
+            uint32_t parent = fbits(P.o[r].w);
+            F3 direct = f3(qd);
+            point = f3(qp);
+            F3 normal = f3(qn);
+            int mat = (int)fbits(qn.w);
+            const float4* M = S.mats + 4 * (size_t)mat;
+            float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+            F3 dif = f3(m1), spec = f3(m2), trans = f3(m3);
+            float ns = m0.w, iorf = m1.w;
+            float rval = m0.x, gval = m0.y, bval = m0.z;
+            rval *= S.ambient.x; gval *= S.ambient.y; bval *= S.ambient.z;
+            for (int j = 0; j < S.nl; j++) {
+                const DLight L = S.lights[j];
+                if (P.occl[(uint64_t)h * (uint32_t)S.nl + j]) continue;
+                F3 I; float dist2f;
+                light_dir(L, point, I, dist2f);
+                double dist = (double)dist2f;
+                double dotni = (double)dot3(normal, I);
+                double cosAlpha = (dotni > 0) ? dotni : 0;
+                F3 lc = f3(L.cr, L.cg, L.cb);
+                F3 illum = lc;
+                if (L.type == 2) {
+                    illum = illum * (float)(1.0 / dist);
+                } else if (L.type == 3) {
+                    double alpha = acos(cosAlpha);
+                    if (alpha < (double)L.a1) illum = lc * (float)(1.0 / dist);
+                    else if (alpha > (double)L.a2) illum = f3(0, 0, 0);
+                    else {
+                        double amt = 1 - ((alpha - (double)L.a1) / (double)(L.a2 - L.a1));
+                        illum = lc * (float)((1.0 / dist) * amt);
+                    }
+                }
+                rval = (float)((double)rval + (double)(dif.x * illum.x) * cosAlpha);
+                gval = (float)((double)gval + (double)(dif.y * illum.y) * cosAlpha);
+                bval = (float)((double)bval + (double)(dif.z * illum.z) * cosAlpha);
+                F3 ref = (normal * (float)(2.0 * dotni)) - I;
+                F3 Vv = direct * -1.0f;
+                double powval = (double)dot3(norm3(Vv), norm3(ref));
+                double pspec = (powval < 0.0) ? 0.0 : pow(powval, (double)ns);
+                rval = (float)((double)rval + ((double)spec.x * pspec) * (double)illum.x);
+                gval = (float)((double)gval + ((double)spec.y * pspec) * (double)illum.y);
+                bval = (float)((double)bval + ((double)spec.z * pspec) * (double)illum.z);
+            }
+            F3 irdir = direct * -1.0f;
+            refl = (spec.x != 0 && spec.y != 0 && spec.z != 0);
+            if (refl) rfd = (normal * (2.0f * dot3(normal, irdir))) - irdir;
+            if (trans.x != 0 && trans.y != 0 && trans.z != 0) {
+                double dni = (double)dot3(irdir, normal);
+                double ior = (dni <= 0) ? (double)iorf : 1.0 / (double)iorf;
+                double tir = 1.0 - (ior * ior) * (1.0 - (dni * dni));
+                if (tir >= 0) {
+                    refr = true;
+                    F3 refdir;
+                    if (dni >= 0) refdir = (normal * (float)(ior * dni - __builtin_sqrt(tir))) - (irdir * (float)ior);
+                    else          refdir = (normal * (float)(ior * dni + __builtin_sqrt(tir))) - (irdir * (float)ior);
+                    rad = norm3(refdir);
+                }
+            }
+            bool leaf = !(refl || refr);
+            if (!leaf && g + 1 > S.max_depth) {
+                // children sit past max_depth: each returns the background untraced
+                if (refl) { rval += spec.x * S.bg.x; gval += spec.y * S.bg.y; bval += spec.z * S.bg.z; }
+                if (refr) { rval += trans.x * S.bg.x; gval += trans.y * S.bg.y; bval += trans.z * S.bg.z; }
+                leaf = true;
+            }
+            if (leaf) {
+                deliver(P, g, parent, fbits(qd.w), f3(rval, gval, bval));
+                P.loc[r] = make_float4(rval, gval, bval, 0.0f);
+            } else {
+                uint32_t code = 4u + (((uint32_t)mat << 2) | (refl ? 1u : 0u) | (refr ? 2u : 0u));
+                P.loc[r] = make_float4(rval, gval, bval, bitsf(code));
+                want = (refl ? 1u : 0u) + (refr ? 1u : 0u);
+            }
+        }
+        uint32_t wbase;
+        uint32_t off = wave_alloc(&C->gen_count[g + 1], want, wbase);
+        if (want) {
+            uint64_t at = (uint64_t)next_start + wbase + off;
+            if (at + want > (uint64_t)P.capacity) {
+                C->overflow = 1;
+            } else {
+                if (refl) {
+                    P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
+                    P.d[at] = make_float4(rfd.x, rfd.y, rfd.z, bitsf(0u));
+                    at++;
+                }
+                if (refr) {
+                    P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
+                    P.d[at] = make_float4(rad.x, rad.y, rad.z, bitsf(1u));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- resolve (bottom-up)
+// Adds the children's colours in the reference's order -- reflection first
+// (src/raytrace.cpp:594-596), then refraction (:625-627) -- and returns the sum
+// to the parent.
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounters* C, int g) {
+    const uint32_t start = gen_start(C, g);
+    const uint32_t count = gen_size(C, g, start, P.capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        uint32_t r = start + i;
+        float4 l = P.loc[r];
+        uint32_t code = fbits(l.w);
+        if (code < 4u) continue;
+        code -= 4u;
+        const float4* M = S.mats + 4 * (size_t)(code >> 2);
+        float rval = l.x, gval = l.y, bval = l.z;
+        if (code & 1u) {
+            float4 s = M[2], c = P.cre[r];
+            rval += s.x * c.x; gval += s.y * c.y; bval += s.z * c.z;
+        }
+        if (code & 2u) {
+            float4 t = M[3], c = P.cra[r];
+            rval += t.x * c.x; gval += t.y * c.y; bval += t.z * c.z;
+        }
+        deliver(P, g, fbits(P.o[r].w), fbits(P.d[r].w), f3(rval, gval, bval));
+    }
+}
+
+// ---------------------------------------------------------------- finish
+// ave (src/raytrace.cpp:1079-1089) then Pixel::SetClamp(c*255.0)
+// (src/raytrace.cpp:112, src/pixel.cpp:38-43): (int) truncation as x86-64
+// performs it (NaN and out-of-range become INT_MIN), then clamp to 0..255.
+__device__ inline uint8_t quantise(float c) {
+    double v = (double)c * 255.0;
+    int i;
+    if (!(v == v) || v >= 2147483648.0 || v <= -2147483649.0) i = (-2147483647 - 1);
+    else i = (int)v;
+    return (uint8_t)((i < 0) ? 0 : (i > 255) ? 255 : i);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_finish(DCamera cam, DPool P, const uint32_t* tiles,
+                                                     uint32_t tile0, uint32_t npixels, int shard_mode,
+                                                     uint8_t* out, float* outf) {
+    for (uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x; lp < npixels; lp += gridDim.x * blockDim.x) {
+        int x, y, px, py; uint32_t tile;
+        pixel_of(tiles, tile0, lp, x, y, px, py, tile);
+        if (x >= cam.width || y >= cam.height) continue;
+        const float4* c = P.scol + (size_t)lp * (uint32_t)cam.spp;
+        F3 u = f3(c[0]);
+        if (cam.spp > 1) {
+            for (int j = 1; j < cam.spp; j++) u = u + f3(c[j]);
+            u = u / (float)cam.spp;
+        }
+        size_t at = shard_mode ? ((size_t)tile * RT_TILE_AREA + (size_t)py * RT_TILE_PX + px)
+                               : ((size_t)y * cam.width + x);
+        if (out) {
+            out[3 * at] = quantise(u.x); out[3 * at + 1] = quantise(u.y); out[3 * at + 2] = quantise(u.z);
+        }
+        if (outf) { outf[3 * at] = u.x; outf[3 * at + 1] = u.y; outf[3 * at + 2] = u.z; }
+    }
+}
+
+// Packed shard buffers of all ranks -> row-major frame.  rowbase[rank*nty + ty] =
+// index (in the rank's tile order) of the first tile the rank owns in tile row ty.
+__global__ void k_assemble(const uint8_t* all, size_t shard_bytes, int world, int width, int height,
+                           int ntx, int nty, const uint32_t* rowbase, uint8_t* out) {
+    size_t n = (size_t)width * height;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(i / width), x = (int)(i - (size_t)y * width);
+        int tx = x / RT_TILE_PX, ty = y / RT_TILE_PX;
+        int rank = (tx + 3 * ty) % world;
+        int first = ((rank - 3 * ty) % world + world) % world;   // first tx owned in this row
+        uint32_t local = rowbase[rank * nty + ty] + (uint32_t)((tx - first) / world);
+        size_t src = (size_t)rank * shard_bytes +
+                     3 * ((size_t)local * RT_TILE_AREA + (size_t)(y % RT_TILE_PX) * RT_TILE_PX + (x % RT_TILE_PX));
+        out[3 * i] = all[src]; out[3 * i + 1] = all[src + 1]; out[3 * i + 2] = all[src + 2];
+    }
+}
+
+// ---------------------------------------------------------------- ray queries (validation)
+template <int ACCEL, bool ANY>
+__global__ __launch_bounds__(RT_BLOCK) void k_query(DScene S, int64_t n, const float* o, const float* d,
+                                                    const float* dmax, int* prim_out, float* d2_out) {
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
+    unsigned long long nodes = 0, tested = 0;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = base + threadIdx.x;
+        bool active = i < n;
+        int64_t ii = active ? i : 0;
+        F3 ro = f3(o[3 * ii], o[3 * ii + 1], o[3 * ii + 2]);
+        F3 rd = f3(d[3 * ii], d[3 * ii + 1], d[3 * ii + 2]);
+        float dm = dmax ? dmax[ii] : __builtin_inff();
+        int best; float best_d2;
+        trace<ACCEL, ANY>(S, lds, active, ro, rd, dm, best, best_d2, nodes, tested);
+        if (active) {
+            prim_out[i] = best;
+            if (d2_out) d2_out[i] = best >= 0 ? best_d2 : __builtin_inff();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+static inline int grid_for(uint64_t items, int max_blocks) {
+    uint64_t b = (items + RT_BLOCK - 1) / RT_BLOCK;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples) {
+    hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(128), 0, st, C, nsamples);
+}
+void rtk_generate(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles,
+                  uint32_t tile0, uint32_t nsamples, int max_blocks) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(nsamples, max_blocks)), dim3(RT_BLOCK), 0, st, cam, P,
+                       tiles, tile0, nsamples);
+}
+void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
+                uint64_t bound, int max_blocks) {
+    dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
+    if (accel == 1) hipLaunchKernelGGL(k_extend<1>, grid, block, 0, st, S, P, C, g);
+    else hipLaunchKernelGGL(k_extend<2>, grid, block, 0, st, S, P, C, g);
+}
+void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
+                uint64_t bound, int max_blocks) {
+    if (S.nl == 0) return;
+    dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
+    if (accel == 1) hipLaunchKernelGGL(k_shadow<1>, grid, block, 0, st, S, P, C, g);
+    else hipLaunchKernelGGL(k_shadow<2>, grid, block, 0, st, S, P, C, g);
+}
+void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
+               int max_blocks) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
+}
+void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
+                 int max_blocks) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
+}
+void rtk_finish(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles, uint32_t tile0,
+                uint32_t npixels, int shard_mode, uint8_t* out, float* outf, int max_blocks) {
+    hipLaunchKernelGGL(k_finish, dim3(grid_for(npixels, max_blocks)), dim3(RT_BLOCK), 0, st, cam, P, tiles,
+                       tile0, npixels, shard_mode, out, outf);
+}
+void rtk_assemble(hipStream_t st, const uint8_t* all, size_t shard_bytes, int world, int width, int height,
+                  int ntx, int nty, const uint32_t* rowbase, uint8_t* out) {
+    hipLaunchKernelGGL(k_assemble, dim3(grid_for((uint64_t)width * height, 4096)), dim3(RT_BLOCK), 0, st, all,
+                       shard_bytes, world, width, height, ntx, nty, rowbase, out);
+}
+void rtk_query(hipStream_t st, int accel, int any_hit, const DScene& S, int64_t n, const float* o,
+               const float* d, const float* dmax, int* prim_out, float* d2_out) {
+    dim3 grid(grid_for((uint64_t)n, 2048)), block(RT_BLOCK);
+    if (accel == 1) {
+        if (any_hit) hipLaunchKernelGGL((k_query<1, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+        else hipLaunchKernelGGL((k_query<1, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+    } else {
+        if (any_hit) hipLaunchKernelGGL((k_query<2, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+        else hipLaunchKernelGGL((k_query<2, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+    }
+}
+void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* x, const int* y,
+                      const int* j, float* o_out, float* d_out) {
+    hipLaunchKernelGGL(k_primary_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cam, n, x, y, j,
+                       o_out, d_out);
+}

@@ -1,0 +1,223 @@
+// GPU LBVH over spheres + triangles for gfx950.
+//
+// Stands where the reference's BVH::make stood (src/raytrace.cpp:652-788), which
+// is incomplete (it drops large triangles) and is not reproduced.  Built fresh:
+//   1. per-primitive padded AABB + scene bounds (block reduce + float atomics)
+//   2. 63-bit Morton code of the box centre (21 bits per axis)
+//   3. radix sort of (code, primitive id) pairs            [rocPRIM device sort]
+//   4. Karras 2012: one thread per inner node finds its key range and split
+//   5. bottom-up refit: the second thread to arrive at a node merges the boxes
+// The tree only has to be CONSERVATIVE: traversal re-runs the reference's exact
+// primitive tests, so the image equals brute force however the tree is shaped.
+//
+// Node i = 4 float4: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (ref0, ref1, -, -)
+// ref >= 0: inner node, ref < 0: leaf = sorted primitive slot ~ref.
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+struct Box { float lo[3], hi[3]; };
+
+// Triangle record (a.xyz, ab.x)(ab.yz, ac.xy)(ac.z, ...) -> the three corners the
+// exact test spans: a, a - ab, a - ac.
+__device__ inline Box prim_box(const float4* sph, int ns, const float4* tri, int p) {
+    Box b;
+    if (p < ns) {
+        float4 s = sph[p];
+        float r = fabsf(s.w);
+        b.lo[0] = s.x - r; b.lo[1] = s.y - r; b.lo[2] = s.z - r;
+        b.hi[0] = s.x + r; b.hi[1] = s.y + r; b.hi[2] = s.z + r;
+    } else {
+        const float4* t = tri + 3 * (size_t)(p - ns);
+        float4 q0 = t[0], q1 = t[1], q2 = t[2];
+        float a[3] = {q0.x, q0.y, q0.z}, ab[3] = {q0.w, q1.x, q1.y}, ac[3] = {q1.z, q1.w, q2.x};
+        for (int k = 0; k < 3; k++) {
+            float v1 = a[k] - ab[k], v2 = a[k] - ac[k];
+            b.lo[k] = fminf(a[k], fminf(v1, v2));
+            b.hi[k] = fmaxf(a[k], fmaxf(v1, v2));
+        }
+    }
+    // pad: the exact tests accept hits a few ulps outside the ideal primitive
+    float m = 0.0f;
+    for (int k = 0; k < 3; k++) m = fmaxf(m, fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k])));
+    float pad = m * 1e-4f + 1e-30f;
+    for (int k = 0; k < 3; k++) { b.lo[k] -= pad; b.hi[k] += pad; }
+    return b;
+}
+
+// order-preserving float <-> uint map so atomicMin/Max on uints reduce floats
+__device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ inline float ord2f(uint32_t u) {
+    uint32_t v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(v);
+#else
+    float f; memcpy(&f, &v, 4); return f;
+#endif
+}
+
+__global__ void k_bounds(const float4* sph, int ns, const float4* tri, int n, Box* boxes, uint32_t* scene /*[6]*/) {
+    __shared__ uint32_t red[6];
+    if (threadIdx.x < 6) red[threadIdx.x] = (threadIdx.x < 3) ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        Box b = prim_box(sph, ns, tri, p);
+        boxes[p] = b;
+        for (int k = 0; k < 3; k++) {
+            float c = 0.5f * (b.lo[k] + b.hi[k]);
+            if (c == c) { atomicMin(&red[k], f2ord(c)); atomicMax(&red[3 + k], f2ord(c)); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&scene[threadIdx.x], red[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&scene[threadIdx.x], red[threadIdx.x]);
+}
+
+__device__ inline unsigned long long spread21(unsigned long long x) {
+    x &= 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void k_morton(const Box* boxes, int n, const uint32_t* scene, unsigned long long* keys, uint32_t* vals) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    unsigned long long code = 0;
+    for (int k = 0; k < 3; k++) {
+        float lo = ord2f(scene[k]), hi = ord2f(scene[3 + k]);
+        float c = 0.5f * (boxes[p].lo[k] + boxes[p].hi[k]);
+        float ext = hi - lo;
+        float u = (ext > 0.0f) ? (c - lo) / ext : 0.0f;
+        if (!(u >= 0.0f)) u = 0.0f;
+        if (u > 1.0f) u = 1.0f;
+        unsigned long long q = (unsigned long long)fminf(u * 2097152.0f, 2097151.0f);
+        code |= spread21(q) << (2 - k);
+    }
+    keys[p] = code;
+    vals[p] = (uint32_t)p;
+}
+
+// Karras 2012, "Maximizing Parallelism in the Construction of BVHs, Octrees, and
+// k-d Trees": common-prefix length of sorted keys i and j, ties broken by index.
+__device__ inline int delta(const unsigned long long* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+__global__ void k_hierarchy(const unsigned long long* keys, int n, int* child /*[2*(n-1)]*/,
+                            int* parent_inner /*[n-1]*/, int* parent_leaf /*[n]*/) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    int c0 = (lo == gamma) ? ~gamma : gamma;
+    int c1 = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    child[2 * i] = c0;
+    child[2 * i + 1] = c1;
+    if (c0 >= 0) parent_inner[c0] = 2 * i; else parent_leaf[~c0] = 2 * i;
+    if (c1 >= 0) parent_inner[c1] = 2 * i + 1; else parent_leaf[~c1] = 2 * i + 1;
+    if (i == 0) parent_inner[0] = -1;
+}
+
+__device__ inline void store_child_box(float4* nodes, int node, int side, const Box& b) {
+    float* f = (float*)(nodes + 4 * (size_t)node);
+    float* dst = f + 6 * side;   // floats 0..5 = box 0, 6..11 = box 1
+    dst[0] = b.lo[0]; dst[1] = b.lo[1]; dst[2] = b.lo[2];
+    dst[3] = b.hi[0]; dst[4] = b.hi[1]; dst[5] = b.hi[2];
+}
+
+__global__ void k_refit(const Box* boxes, const uint32_t* sorted, int n, const int* child, const int* parent_inner,
+                        const int* parent_leaf, uint32_t* flags, float4* nodes) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Box b = boxes[sorted[j]];
+    int link = parent_leaf[j];
+    while (link >= 0) {
+        int node = link >> 1, side = link & 1;
+        store_child_box(nodes, node, side, b);
+        __threadfence();
+        uint32_t old = atomicAdd(&flags[node], 1u);
+        if (old == 0) return;                 // first arrival: the sibling's thread continues
+        __threadfence();
+        // second arrival: both child boxes are in place; read the sibling's through L2
+        const float* f = (const float*)(nodes + 4 * (size_t)node);
+        const float* sib = f + 6 * (1 - side);
+        for (int k = 0; k < 3; k++) {
+            float slo = __hip_atomic_load(&sib[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float shi = __hip_atomic_load(&sib[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b.lo[k] = fminf(b.lo[k], slo);
+            b.hi[k] = fmaxf(b.hi[k], shi);
+        }
+        // child references live in the last float4 of the node
+        int* refs = (int*)(nodes + 4 * (size_t)node + 3);
+        refs[0] = child[2 * node]; refs[1] = child[2 * node + 1]; refs[2] = 0; refs[3] = 0;
+        link = parent_inner[node];
+    }
+}
+
+#define L_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(vals2); return (int)e_; } } while (0)
+
+int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
+              int** prim_idx_out, int* root) {
+    int n = ns + nt;
+    *nodes_out = nullptr; *prim_idx_out = nullptr; *root = 0;
+    if (n < 2) return (int)hipErrorInvalidValue;
+    Box* boxes = nullptr; uint32_t* scene = nullptr;
+    unsigned long long *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;
+    int *child = nullptr, *pin = nullptr, *plf = nullptr; uint32_t* flags = nullptr; void* tmp = nullptr;
+    float4* nodes = nullptr;
+    auto cleanup = [&]() {
+        void* ptrs[] = {boxes, scene, keys, keys2, vals, child, pin, plf, flags, tmp};
+        for (void* p : ptrs) (void)hipFree(p);
+    };
+    L_TRY(hipMalloc(&boxes, (size_t)n * sizeof(Box)));
+    L_TRY(hipMalloc(&scene, 6 * sizeof(uint32_t)));
+    L_TRY(hipMalloc(&keys, (size_t)n * 8)); L_TRY(hipMalloc(&keys2, (size_t)n * 8));
+    L_TRY(hipMalloc(&vals, (size_t)n * 4)); L_TRY(hipMalloc(&vals2, (size_t)n * 4));
+    L_TRY(hipMalloc(&child, (size_t)(n - 1) * 2 * sizeof(int)));
+    L_TRY(hipMalloc(&pin, (size_t)(n - 1) * sizeof(int)));
+    L_TRY(hipMalloc(&plf, (size_t)n * sizeof(int)));
+    L_TRY(hipMalloc(&flags, (size_t)(n - 1) * sizeof(uint32_t)));
+    L_TRY(hipMalloc(&nodes, (size_t)(n - 1) * 4 * sizeof(float4)));
+    uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    L_TRY(hipMemcpyAsync(scene, init, sizeof(init), hipMemcpyHostToDevice, st));
+    L_TRY(hipMemsetAsync(flags, 0, (size_t)(n - 1) * sizeof(uint32_t), st));
+    int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, sph, ns, tri, n, boxes, scene);
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, st, boxes, n, scene, keys, vals);
+    size_t tmp_bytes = 0;
+    L_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, st));
+    L_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+    L_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, st));
+    hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, st, keys2, n, child, pin, plf);
+    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, boxes, vals2, n, child, pin, plf, flags, nodes);
+    L_TRY(hipGetLastError());
+    L_TRY(hipStreamSynchronize(st));
+    cleanup();
+    *nodes_out = nodes;
+    *prim_idx_out = (int*)vals2;   // sorted primitive ids, kept by the caller
+    *root = 0;
+    return (int)hipSuccess;
+}

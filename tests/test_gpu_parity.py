@@ -1,0 +1,197 @@
+"""GPU suite (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle run
+live on the same inputs and against the committed reference renders.
+
+Tolerance.  The contract is <= 1 LSB per 8-bit channel on >= 99.9 % of pixels.  The HIP
+kernels restate the reference's arithmetic operation for operation, so the tests demand
+more: float colours bit-identical on >= 99.9 % of pixels (the only licensed difference is
+the device libm rounding pow()/acos() differently from glibc in the last place), RGB8
+within 1 LSB everywhere, and identical per-class ray counts."""
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+from conftest import bits, golden_cases, load_case, load_scene, same_float_image
+
+pytestmark = pytest.mark.gpu
+
+EXACT_FRACTION = 0.999      # pixels whose float colour must be bit-identical
+LSB_FRACTION = 1.0          # pixels whose RGB8 must be within 1 LSB
+
+
+def crop(img, roi):
+    x0, y0, x1, y1 = roi
+    return img[y0:y1, x0:x1]
+
+
+def check_image(rgb, rgbf, gold_rgb, gold_rgbf, what):
+    same = same_float_image(rgbf, gold_rgbf).all(axis=2)
+    frac = same.mean()
+    lsb = (np.abs(rgb.astype(np.int32) - gold_rgb.astype(np.int32)) <= 1).all(axis=2).mean()
+    assert lsb >= LSB_FRACTION, f"{what}: only {lsb:.6f} of pixels within 1 LSB"
+    assert frac >= EXACT_FRACTION, f"{what}: only {frac:.6f} of pixels bit-identical in float"
+    return frac
+
+
+@pytest.mark.parametrize("accel", [ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH])
+@pytest.mark.parametrize("case", golden_cases())
+def test_render_matches_reference_fixture_and_oracle(oracle, case, accel):
+    scene, roi, gold = load_case(case)
+    if accel == ra.RT_ACCEL_LBVH and len(scene.spheres) + len(scene.tri_verts) < 2:
+        pytest.skip("LBVH needs two primitives")
+    with ra.Tracer(accel=accel) as t:
+        t.load_scene(scene)
+        rgb, rgbf, st = t.render(want_float=True)
+    check_image(crop(rgb, roi), crop(rgbf, roi), gold["rgb"], gold["rgbf"], f"{case} vs reference fixture")
+    full = roi == (0, 0, scene.width, scene.height)
+    if full:
+        assert [st.rays_primary, st.rays_secondary, st.rays_shadow] == [int(v) for v in gold["counts"]]
+        assert st.accel_used == accel
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("spheres1", 640, 480, 1), ("outdoor_spot", 480, 270, 4),
+                                          ("spheres2", 200, 150, 5), ("test_reasonable", 320, 240, 2)])
+def test_larger_frames_against_live_oracle(oracle, tracer, name, w, h, spp):
+    scene = load_scene(name).copy(width=w, height=h, spp=spp, seed=11)
+    tracer.load_scene(scene)
+    rgb, rgbf, st = tracer.render(want_float=True)
+    orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
+    check_image(rgb, rgbf, orgb, orgbf, f"{name} vs live oracle")
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow)
+
+
+def test_k1_ray_count_pin(tracer):
+    tracer.load_scene(load_scene("spheres1"))
+    rgb, _, st = tracer.render()
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (307200, 1267376, 805513)
+    assert tuple(rgb[0, 0]) == (12, 12, 12)
+
+
+@pytest.mark.parametrize("key,scene_name,spp", [("spheres1_spp1", "spheres1", 1), ("spheres1_spp5", "spheres1", 5),
+                                                ("outdoor_spp3", "outdoor", 3), ("dragon_spp1", "dragon", 1)])
+def test_primary_rays_and_closest_hits_known_answers(oracle, tracer, kat, key, scene_name, spp):
+    scene = load_scene(scene_name).copy(spp=spp)
+    tracer.load_scene(scene)
+    xyj = kat[f"ray_{key}_xyj"]
+    o, d = tracer.primary_rays(xyj[:, 0], xyj[:, 1], xyj[:, 2])
+    assert np.array_equal(bits(o), bits(kat[f"ray_{key}_o"]))
+    assert np.array_equal(bits(d), bits(kat[f"ray_{key}_d"]))
+    ref_hit = kat[f"hit_{key}"]
+    want_prim, want_d2 = oracle.intersect_many(scene, o, d)
+    for accel in (ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH):
+        prim, d2 = tracer.query_rays(o, d, accel=accel)
+        assert np.array_equal(prim >= 0, ref_hit[:, 0] != 0)
+        assert np.array_equal(prim, want_prim)
+        hit = prim >= 0
+        assert np.array_equal(d2[hit].astype(np.float64), ref_hit[hit, 4])   # reference dist (squared)
+
+
+def _random_rays(scene, n, rng):
+    prim_pts = []
+    if len(scene.spheres):
+        prim_pts.append(scene.spheres[:, :3])
+    if len(scene.tri_verts):
+        prim_pts.append(scene.tri_verts.reshape(-1, 3))
+    pts = np.concatenate(prim_pts)
+    lo, hi = pts.min(0), pts.max(0)
+    ext = np.maximum(hi - lo, 1e-3)
+    o = (lo - ext) + rng.random((n, 3)) * 3 * ext
+    tgt = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.02, (n, 3)) * ext
+    d = tgt - o
+    d *= rng.uniform(0.2, 3.0, (n, 1)) / np.linalg.norm(d, axis=1, keepdims=True)   # un-normalised on purpose
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["dragon", "plant_h", "complex_test", "spheres2"])
+def test_lbvh_equals_brute_force_on_random_rays(tracer, name):
+    scene = load_scene(name)
+    tracer.load_scene(scene)
+    rng = np.random.default_rng(5)
+    n = 200_000
+    o, d = _random_rays(scene, n, rng)
+    pb, db = tracer.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
+    pl, dl = tracer.query_rays(o, d, accel=ra.RT_ACCEL_LBVH)
+    assert (pb >= 0).mean() > 0.2, "ray generator barely hits the scene"
+    assert np.array_equal(pb, pl), f"{(pb != pl).sum()} of {n} closest hits differ"
+    assert np.array_equal(bits(db), bits(dl))
+    # any-hit with a finite window (the shadow query): same yes/no
+    dmax = np.where(rng.random(n) < 0.5, db * rng.uniform(0.5, 1.5, n).astype(np.float32), np.float32(np.inf)).astype(np.float32)
+    dmax[~np.isfinite(dmax)] = np.inf
+    ab, _ = tracer.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_BRUTE)
+    al, _ = tracer.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_LBVH)
+    assert np.array_equal(ab >= 0, al >= 0)
+
+
+def test_query_matches_oracle_on_random_rays(oracle, tracer):
+    scene = load_scene("complex_test")
+    tracer.load_scene(scene)
+    o, d = _random_rays(scene, 3000, np.random.default_rng(9))
+    want_prim, want_d2 = oracle.intersect_many(scene, o, d)
+    prim, d2 = tracer.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
+    assert np.array_equal(prim, want_prim)
+    assert np.array_equal(bits(d2[prim >= 0]), bits(want_d2[prim >= 0]))
+
+
+def test_image_is_independent_of_batching_and_pool_overflow_retries():
+    scene = load_scene("spheres1").copy(width=320, height=240, spp=2)
+    imgs = []
+    for kw in ({}, {"batch_samples": 4096}, {"batch_samples": 65536, "pool_rays": 70000}):
+        with ra.Tracer(**kw) as t:
+            t.load_scene(scene)
+            rgb, rgbf, st = t.render(want_float=True)
+            imgs.append((rgb, rgbf, st))
+    assert imgs[2][2].retries > 0, "the small pool was meant to overflow and retry"
+    for rgb, rgbf, st in imgs[1:]:
+        assert np.array_equal(bits(rgbf), bits(imgs[0][1])) and np.array_equal(rgb, imgs[0][0])
+        assert (st.rays_secondary, st.rays_shadow) == (imgs[0][2].rays_secondary, imgs[0][2].rays_shadow)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_sharded_render_is_byte_identical_for_any_world_size(tracer, world):
+    import torch
+    from raytracer_amd import dist as rd
+    scene = load_scene("outdoor_spot").copy(width=200, height=150, spp=2)
+    tracer.load_scene(scene)
+    full, _, st_full = tracer.render()
+    sb = ra.shard_bytes(scene.width, scene.height, world)
+    allsh = torch.zeros(world * sb, dtype=torch.uint8, device="cuda:0")
+    rays = 0
+    for r in range(world):
+        st = tracer.render_shard(r, world, allsh[r * sb:(r + 1) * sb].data_ptr())
+        rays += st.rays
+        torch.cuda.synchronize()
+        # the packed layout is the one the host mirror (used by the gloo test) produces
+        n = ra.shard_tiles(scene.width, scene.height, r, world) * ra.RT_TILE * ra.RT_TILE * 3
+        host = rd.pack_shard_host(full, r, world)
+        got = allsh[r * sb:(r + 1) * sb].cpu().numpy()
+        tiles = rd.tile_list(scene.width, scene.height, r, world)
+        for i, (tx, ty) in enumerate(tiles):
+            hh = min(ra.RT_TILE, scene.height - ty * ra.RT_TILE); ww = min(ra.RT_TILE, scene.width - tx * ra.RT_TILE)
+            a = got[: n].reshape(-1, ra.RT_TILE, ra.RT_TILE, 3)[i, :hh, :ww]
+            b = host[: n].reshape(-1, ra.RT_TILE, ra.RT_TILE, 3)[i, :hh, :ww]
+            assert np.array_equal(a, b)
+    assert rays == st_full.rays
+    frame = torch.zeros((scene.height, scene.width, 3), dtype=torch.uint8, device="cuda:0")
+    tracer.assemble_shards(allsh.data_ptr(), world, frame.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full)
+    assert np.array_equal(rd.assemble_host(allsh.cpu().numpy(), world, scene.width, scene.height), full)
+
+
+def test_edge_cases(tracer):
+    # empty scene: background everywhere, no secondary or shadow rays
+    s = ra.SceneArrays(width=70, height=33, background=np.array([.25, .5, 1], np.float32))
+    tracer.load_scene(s)
+    rgb, _, st = tracer.render()
+    assert (rgb == np.array([63, 127, 255], np.uint8)).all() and st.rays == 70 * 33
+    # one sphere, no light, NaN-producing zero direction camera is not used; depth 0 cuts all recursion
+    s = load_scene("spheres1").copy(width=64, height=48, max_depth=0)
+    tracer.load_scene(s)
+    _, _, st = tracer.render()
+    assert st.rays_secondary == 0 and st.generations == 1
+    # errors, not crashes
+    with ra.Tracer() as t:
+        with pytest.raises(ra.RtError):
+            t.render()
+        bad = load_scene("spheres1").copy(max_depth=200)
+        with pytest.raises(ra.RtError):
+            t.load_scene(bad)

@@ -1,0 +1,75 @@
+"""CPU suite, build container only: the oracle and the product's parser against the
+unmodified reference (oracle/_ref/libref_oracle.so built from /root/reference/src).
+Skipped where that library or the reference tree is absent."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+from _oracle import REFERENCE_TREE, Reference, have_reference
+from conftest import bits, same_float_image
+
+pytestmark = pytest.mark.skipif(not (have_reference() and os.path.isdir(REFERENCE_TREE)),
+                                reason="reference build / tree not present")
+
+# sha256 of the BMP the serial brute-force reference writes at 640x480 (first 16 hex digits)
+PINS = {
+    "SphereExamples/spheres1.scn": "09e1d34c5d168373",
+    "TriangleExamples/outdoor.scn": "d06559d640854d74",
+    "SphereExamples/spot_sphere.scn": "8266005ef7dbf0c5",
+    "SphereExamples/ambient_sphere.scn": "4995cf7734a7ef30",
+    "TriangleExamples/triangle.scn": "5f05c725865b6604",
+    "BVHTest/test.scn": "95f0cfdd034b5122",
+    "TriangleExamples/test_reasonable.scn": "26c88c9542d41c9d",
+}
+ALL_SCENES = list(PINS) + ["SphereExamples/spheres2.scn", "ComplexExamples/dragon.scn", "ComplexExamples/plant-h.scn",
+                           "ComplexExamples/test.scn", "PlaneExamples/test.scn", "PlaneExamples/rect.scn", "src/sphere.scn"]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return Reference()
+
+
+@pytest.mark.parametrize("rel", list(PINS))
+def test_full_frame_bit_identity_and_bmp_pin(ref, oracle, rel, tmp_path):
+    assert ref.load(os.path.join(REFERENCE_TREE, rel)) > 0
+    scene = ref.scene_arrays()
+    rgb_r, rgbf_r, _ = ref.render()
+    rgb_o, rgbf_o, _, _ = oracle.render(scene)
+    assert same_float_image(rgbf_r, rgbf_o).all()
+    assert np.array_equal(rgb_r, rgb_o)
+    # the product's BMP writer on the oracle's pixels reproduces the reference's file
+    out = tmp_path / "o.bmp"
+    ra.write_bmp24(str(out), rgb_o)
+    assert hashlib.sha256(out.read_bytes()).hexdigest()[:16] == PINS[rel]
+    out_ref = tmp_path / "r.bmp"
+    ref.write_bmp(str(out_ref), rgb_r)
+    assert out.read_bytes() == out_ref.read_bytes()
+
+
+@pytest.mark.parametrize("rel", ALL_SCENES)
+def test_product_parser_matches_reference_parser(ref, rel):
+    path = os.path.join(REFERENCE_TREE, rel)
+    assert ref.load(path) > 0
+    a = ref.scene_arrays()
+    b = ra.parse_scene_file(path, ref_compat=True)
+    assert (a.width, a.height, a.spp, a.max_depth, a.proj) == (b.width, b.height, b.spp, b.max_depth, b.proj)
+    for n in ("cam_pos", "cam_dir", "cam_up", "background", "ambient", "spheres", "tri_verts", "tri_normals",
+              "tri_flags", "lights"):
+        x, y = getattr(a, n), getattr(b, n)
+        assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), n
+    assert np.float32(a.cam_half_angle) == np.float32(b.cam_half_angle)
+    assert np.array_equal(bits(a.materials[a.sphere_mat]), bits(b.materials[b.sphere_mat]))
+    assert np.array_equal(bits(a.materials[a.tri_mat]), bits(b.materials[b.tri_mat]))
+    assert a.output_name == b.output_name
+
+
+def test_jittered_supersampling_matches(ref, oracle):
+    assert ref.load(os.path.join(REFERENCE_TREE, "SphereExamples/spheres2.scn"), w=120, h=90, spp=6) > 0
+    scene = ref.scene_arrays(seed=5)
+    _, rgbf_r, _ = ref.render(seed=5)
+    _, rgbf_o, _, _ = oracle.render(scene)
+    assert same_float_image(rgbf_r, rgbf_o).all()
