@@ -99,13 +99,19 @@ typedef struct rt_stats {
     uint64_t rays_primary;     /* rays that reach an intersection query, by class --     */
     uint64_t rays_secondary;   /* the reference's two `intersect` call sites             */
     uint64_t rays_shadow;      /* (src/raytrace.cpp:139 and :536)                        */
-    uint64_t nodes_visited;    /* LBVH: inner-node box tests, closest-hit + any-hit      */
-    uint64_t prims_tested;     /* exact primitive tests                                  */
+    /* traversal work of the closest-hit [0] and any-hit [1] kernels */
+    uint64_t nodes_visited[2]; /* LBVH inner nodes fetched (64 B each)                   */
+    uint64_t sphere_tests[2];  /* exact sphere tests (16 B each)                         */
+    uint64_t tri_tests[2];     /* exact triangle tests (36 B each)                       */
     double ms_render;          /* device time of the whole call (HIP events)             */
+    /* per-stage device time, filled only when the environment variable
+       RT_STAGE_TIMES is set (HIP events between the stage launches) */
     double ms_extend;          /* closest-hit kernels                                    */
     double ms_shadow;          /* any-hit kernels                                        */
     double ms_shade;           /* shading + spawn + compaction kernels                   */
     double ms_other;           /* generate, resolve, finish                              */
+    int32_t launches_extend;   /* kernel launches behind ms_extend / ms_shadow           */
+    int32_t launches_shadow;
     int32_t batches;
     int32_t retries;           /* batches re-run at half size after a ray-pool overflow  */
     int32_t accel_used;        /* RT_ACCEL_BRUTE or RT_ACCEL_LBVH                        */

@@ -58,9 +58,10 @@ class RtOptions(C.Structure):
 
 class RtStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
-                ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
+                ("nodes_visited", C.c_uint64 * 2), ("sphere_tests", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2),
                 ("ms_render", C.c_double), ("ms_extend", C.c_double), ("ms_shadow", C.c_double),
                 ("ms_shade", C.c_double), ("ms_other", C.c_double),
+                ("launches_extend", C.c_int32), ("launches_shadow", C.c_int32),
                 ("batches", C.c_int32), ("retries", C.c_int32), ("accel_used", C.c_int32),
                 ("generations", C.c_int32)]
 
@@ -69,7 +70,8 @@ class RtStats(C.Structure):
         return self.rays_primary + self.rays_secondary + self.rays_shadow
 
     def as_dict(self) -> dict:
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), '__len__') else getattr(self, n))
+                for n, _ in self._fields_}
 
 
 _lib = None
@@ -329,8 +331,9 @@ class Tracer:
     def render(self, want_float: bool = False):
         """-> (rgb8 [H,W,3], rgbf [H,W,3] or None, RtStats); host arrays."""
         s = self.scene
-        rgb = np.zeros((s.height, s.width, 3), np.uint8)
-        rgbf = np.zeros((s.height, s.width, 3), np.float32) if want_float else None
+        h, w = (s.height, s.width) if s is not None else (1, 1)   # no scene: the library reports it
+        rgb = np.zeros((h, w, 3), np.uint8)
+        rgbf = np.zeros((h, w, 3), np.float32) if want_float else None
         st = RtStats()
         rc = self._lib.rt_render(self._ctx, _ptr(rgb), _ptr(rgbf), C.byref(st))
         if rc != RT_OK:

@@ -331,7 +331,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
 // ---------------------------------------------------------------- batch scheduler
 struct BatchResult {
     bool overflow = false;
-    uint64_t secondary = 0, shadow = 0, nodes = 0, prims = 0;
+    uint64_t secondary = 0, shadow = 0, nodes[2] = {0, 0}, sph[2] = {0, 0}, tri[2] = {0, 0};
     int generations = 0;
 };
 
@@ -399,7 +399,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
             res.shadow += (uint64_t)hc.hit_count[g] * (uint64_t)S.nl;
             if (hc.gen_count[g]) res.generations = g + 1;
         }
-        res.nodes = hc.nodes_visited; res.prims = hc.prims_tested;
+        for (int k = 0; k < 2; k++) { res.nodes[k] = hc.nodes[k]; res.sph[k] = hc.sph_tests[k]; res.tri[k] = hc.tri_tests[k]; }
     }
     return RT_OK;
 }
@@ -461,8 +461,11 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         acc.batches++;
         acc.rays_secondary += br.secondary;
         acc.rays_shadow += br.shadow;
-        acc.nodes_visited += br.nodes;
-        acc.prims_tested += br.prims;
+        for (int k = 0; k < 2; k++) {
+            acc.nodes_visited[k] += br.nodes[k]; acc.sphere_tests[k] += br.sph[k]; acc.tri_tests[k] += br.tri[k];
+        }
+        acc.launches_extend += c->S.max_depth + 1;
+        acc.launches_shadow += c->S.nl ? c->S.max_depth + 1 : 0;
         acc.generations = std::max(acc.generations, br.generations);
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

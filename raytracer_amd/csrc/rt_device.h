@@ -96,8 +96,11 @@ struct DCounters {
     uint32_t hit_count[RT_MAX_GEN + 1];   // hits per generation
     uint32_t overflow;                    // set when a spawn did not fit the pool
     uint32_t pad;
-    unsigned long long nodes_visited;
-    unsigned long long prims_tested;
+    // traversal work, closest-hit [0] and any-hit [1] kernels: inner nodes fetched,
+    // sphere tests, triangle tests
+    unsigned long long nodes[2];
+    unsigned long long sph_tests[2];
+    unsigned long long tri_tests[2];
 };
 
 // ---------------------------------------------------------------- jitter

@@ -69,9 +69,13 @@ __device__ inline void deliver(const DPool& P, int g, uint32_t parent, uint32_t 
 // once per ray.  All threads of the block must call (barriers inside).
 #define BRUTE_CHUNK 768   // float4 slots: 768 spheres or 256 triangles per chunk (12 KB)
 
+struct TraceStats {
+    unsigned long long nodes = 0, sph = 0, tri = 0;
+};
+
 template <bool ANY>
 __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
-                                   int& best, float& best_d2, unsigned long long& tested) {
+                                   int& best, float& best_d2, TraceStats& ts) {
     double dd = (double)dot3(d, d);
     best = -1;
     best_d2 = dmax;
@@ -89,7 +93,7 @@ __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3
                     if (ANY) { done = true; break; }
                 }
             }
-            tested += n;
+            ts.sph += n;
         }
     }
     for (int base = 0; base < S.nt; base += BRUTE_CHUNK / 3) {
@@ -107,7 +111,7 @@ __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3
                     if (ANY) { done = true; break; }
                 }
             }
-            tested += n;
+            ts.tri += n;
         }
     }
 }
@@ -140,7 +144,7 @@ __device__ inline bool box_hit(F3 lo, F3 hi, F3 o, F3 inv, float tmax, float& tn
 
 template <bool ANY>
 __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
-                                  float& best_d2, unsigned long long& nodes, unsigned long long& tested) {
+                                  float& best_d2, TraceStats& ts) {
     best = -1;
     best_d2 = dmax;
     if (!active) return;
@@ -156,7 +160,7 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
         if (cur >= 0) {
             const float4* nd = S.nodes + 4 * (size_t)cur;
             float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            nodes++;
+            ts.nodes++;
             float tn0, tn1;
             bool h0 = box_hit(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), o, inv, tmax, tn0);
             bool h1 = box_hit(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), o, inv, tmax, tn1);
@@ -171,16 +175,17 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
             else if (h1) { cur = c1; continue; }
         } else {
             int prim = S.prim_idx[~cur];
-            tested++;
             bool hit = false;
             float d2 = 0;
             if (prim < S.ns) {
                 float tf;
+                ts.sph++;
                 hit = sphere_test(o, d, dd, S.sph[prim], dmax, d2, tf);
             } else {
                 F3 a, ab, ac;
                 tri_load(S.tri + 3 * (size_t)(prim - S.ns), a, ab, ac);
                 TriHit h;
+                ts.tri++;
                 hit = tri_test(o, d, a, ab, ac, dmax, h);
                 d2 = h.d2;
             }
@@ -200,20 +205,21 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
 
 template <int ACCEL, bool ANY>
 __device__ inline void trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
-                             int& best, float& best_d2, unsigned long long& nodes,
-                             unsigned long long& tested) {
-    if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, tested);
-    else lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, nodes, tested);
+                             int& best, float& best_d2, TraceStats& ts) {
+    if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, ts);
+    else lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, ts);
 }
 
-__device__ inline void flush_stats(DCounters* C, unsigned long long nodes, unsigned long long tested) {
+__device__ inline void flush_stats(DCounters* C, int which, TraceStats ts) {
     for (int off = 32; off > 0; off >>= 1) {
-        nodes += __shfl_down(nodes, off);
-        tested += __shfl_down(tested, off);
+        ts.nodes += __shfl_down(ts.nodes, off);
+        ts.sph += __shfl_down(ts.sph, off);
+        ts.tri += __shfl_down(ts.tri, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (nodes) atomicAdd(&C->nodes_visited, nodes);
-        if (tested) atomicAdd(&C->prims_tested, tested);
+        if (ts.nodes) atomicAdd(&C->nodes[which], ts.nodes);
+        if (ts.sph) atomicAdd(&C->sph_tests[which], ts.sph);
+        if (ts.tri) atomicAdd(&C->tri_tests[which], ts.tri);
     }
 }
 
@@ -280,7 +286,8 @@ __global__ void k_primary_rays(DCamera cam, int64_t n, const int* x, const int* 
 __global__ void k_init_counters(DCounters* C, uint32_t nsamples) {
     int i = threadIdx.x;
     if (i <= RT_MAX_GEN) { C->gen_count[i] = (i == 0) ? nsamples : 0; C->hit_count[i] = 0; }
-    if (i == 0) { C->overflow = 0; C->pad = 0; C->nodes_visited = 0; C->prims_tested = 0; }
+    if (i == 0) { C->overflow = 0; C->pad = 0; }
+    if (i < 2) { C->nodes[i] = 0; C->sph_tests[i] = 0; C->tri_tests[i] = 0; }
 }
 
 // ---------------------------------------------------------------- extend (closest hit)
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounter
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
-    unsigned long long nodes = 0, tested = 0;
+    TraceStats ts;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
         uint32_t i = base + threadIdx.x;
         bool inrange = i < count;
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounter
         bool active = inrange && !(g == 0 && parent == 0xFFFFFFFFu);
         F3 o = f3(qo), d = f3(qd);
         int best; float best_d2;
-        trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, nodes, tested);
+        trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, ts);
         bool hit = active && best >= 0;
         if (hit) {
             F3 point, normal; int mat;
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounter
         uint32_t off = wave_alloc(&C->hit_count[g], hit ? 1u : 0u, wbase);
         if (hit) P.hitlist[start + wbase + off] = r;
     }
-    flush_stats(C, nodes, tested);
+    flush_stats(C, 0, ts);
 }
 
 // ---------------------------------------------------------------- shadow (any hit)
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounter
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
     const uint64_t items = (uint64_t)nh * (uint64_t)S.nl;
-    unsigned long long nodes = 0, tested = 0;
+    TraceStats ts;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items;
          base += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t k = base + threadIdx.x;
@@ -342,10 +349,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounter
         F3 I; float dist2;
         light_dir(S.lights[j], point, I, dist2);
         int best; float best_d2;
-        trace<ACCEL, true>(S, lds, active, point, I, dist2, best, best_d2, nodes, tested);
+        trace<ACCEL, true>(S, lds, active, point, I, dist2, best, best_d2, ts);
         if (active) P.occl[k] = (best >= 0) ? 1 : 0;
     }
-    flush_stats(C, nodes, tested);
+    flush_stats(C, 1, ts);
 }
 
 // ---------------------------------------------------------------- shade + spawn
@@ -545,7 +552,7 @@ template <int ACCEL, bool ANY>
 __global__ __launch_bounds__(RT_BLOCK) void k_query(DScene S, int64_t n, const float* o, const float* d,
                                                     const float* dmax, int* prim_out, float* d2_out) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
-    unsigned long long nodes = 0, tested = 0;
+    TraceStats ts;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
         int64_t i = base + threadIdx.x;
         bool active = i < n;
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_query(DScene S, int64_t n, const f
         F3 rd = f3(d[3 * ii], d[3 * ii + 1], d[3 * ii + 2]);
         float dm = dmax ? dmax[ii] : __builtin_inff();
         int best; float best_d2;
-        trace<ACCEL, ANY>(S, lds, active, ro, rd, dm, best, best_d2, nodes, tested);
+        trace<ACCEL, ANY>(S, lds, active, ro, rd, dm, best, best_d2, ts);
         if (active) {
             prim_out[i] = best;
             if (d2_out) d2_out[i] = best >= 0 ? best_d2 : __builtin_inff();
