@@ -43,7 +43,8 @@ enum { RT_LIGHT_AMBIENT = 0, RT_LIGHT_DIRECTIONAL = 1, RT_LIGHT_POINT = 2, RT_LI
 /* Projection: numeric values of the reference's enum ProjType (src/parse.h:13-16). */
 enum { RT_PROJ_ORTHO = 0, RT_PROJ_PERSP = 1 };
 /* Acceleration structure selection. */
-enum { RT_ACCEL_AUTO = 0, RT_ACCEL_BRUTE = 1, RT_ACCEL_LBVH = 2 };
+enum { RT_ACCEL_AUTO = 0, RT_ACCEL_BRUTE = 1, RT_ACCEL_LBVH = 2,
+       RT_ACCEL_LBVH_PACKET = 3 /* rt_query_rays only: force the wave-packet walk of the LBVH */ };
 
 /* One light: the fields of the reference's class Light (src/parse.h:188-195). */
 typedef struct rt_light {
@@ -90,8 +91,8 @@ typedef struct rt_options {
     int32_t accel;             /* RT_ACCEL_*; AUTO = brute force (LDS-staged) for small
                                   scenes, LBVH above lbvh_threshold primitives          */
     int32_t lbvh_threshold;    /* 0 = default (64)                                      */
-    int32_t batch_samples;     /* pixel-samples traced per wavefront batch, 0 = default */
-    int64_t pool_rays;         /* ray-pool capacity per batch, 0 = default (8 x batch)  */
+    int32_t batch_samples;     /* pixel-samples per wavefront batch, 0 = default (32 Mi)*/
+    int64_t pool_rays;         /* ray-pool capacity per batch, 0 = default (4 x batch)  */
     void* stream;              /* hipStream_t to run on, NULL = a stream the ctx owns   */
 } rt_options;
 
@@ -100,9 +101,12 @@ typedef struct rt_stats {
     uint64_t rays_secondary;   /* the reference's two `intersect` call sites             */
     uint64_t rays_shadow;      /* (src/raytrace.cpp:139 and :536)                        */
     /* traversal work of the closest-hit [0] and any-hit [1] kernels */
-    uint64_t nodes_visited[2]; /* LBVH inner nodes fetched (64 B each)                   */
-    uint64_t sphere_tests[2];  /* exact sphere tests (16 B each)                         */
-    uint64_t tri_tests[2];     /* exact triangle tests (36 B each)                       */
+    uint64_t nodes_visited[2]; /* LBVH inner-node records fetched (64 B each): one per ray
+                                  in the per-lane walk, one per 64-ray wave in the packet walk */
+    uint64_t sphere_tests[2];  /* sphere records fetched (16 B each), same convention    */
+    uint64_t tri_tests[2];     /* triangle records fetched (36 B each), same convention  */
+    uint64_t lane_node_tests[2]; /* box-pair tests computed, counted per ray             */
+    uint64_t lane_prim_tests[2]; /* exact primitive tests computed, counted per ray      */
     double ms_render;          /* device time of the whole call (HIP events)             */
     /* per-stage device time, filled only when the environment variable
        RT_STAGE_TIMES is set (HIP events between the stage launches) */

@@ -20,7 +20,7 @@ RT_OK = 0
  RT_ERR_NO_SCENE) = range(1, 9)
 RT_LIGHT_AMBIENT, RT_LIGHT_DIRECTIONAL, RT_LIGHT_POINT, RT_LIGHT_SPOT = 0, 1, 2, 3
 RT_PROJ_ORTHO, RT_PROJ_PERSP = 0, 1
-RT_ACCEL_AUTO, RT_ACCEL_BRUTE, RT_ACCEL_LBVH = 0, 1, 2
+RT_ACCEL_AUTO, RT_ACCEL_BRUTE, RT_ACCEL_LBVH, RT_ACCEL_LBVH_PACKET = 0, 1, 2, 3
 RT_PARSE_REF_COMPAT = 1
 RT_TILE = 32
 
@@ -59,6 +59,7 @@ class RtOptions(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("nodes_visited", C.c_uint64 * 2), ("sphere_tests", C.c_uint64 * 2), ("tri_tests", C.c_uint64 * 2),
+                ("lane_node_tests", C.c_uint64 * 2), ("lane_prim_tests", C.c_uint64 * 2),
                 ("ms_render", C.c_double), ("ms_extend", C.c_double), ("ms_shadow", C.c_double),
                 ("ms_shade", C.c_double), ("ms_other", C.c_double),
                 ("launches_extend", C.c_int32), ("launches_shadow", C.c_int32),

@@ -58,12 +58,13 @@ struct rt_ctx {
     // scene
     bool has_scene = false;
     int accel = RT_ACCEL_BRUTE;
+    int packet_gens_extend = RT_MAX_GEN, packet_gens_shadow = RT_MAX_GEN;   // see run_batch
     DScene S{};
     DCamera cam{};
     float4* d_sph = nullptr; int* d_sph_mat = nullptr;
     float4* d_tri = nullptr; float4* d_tri_n = nullptr;
     float4* d_mats = nullptr; DLight* d_lights = nullptr;
-    float4* d_nodes = nullptr; int* d_prim_idx = nullptr;
+    float4* d_nodes = nullptr; int* d_prim_idx = nullptr; float4* d_leaf = nullptr;
 
     // ray pool
     DPool P{};
@@ -85,14 +86,16 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c) {
     hipFree(c->d_sph); hipFree(c->d_sph_mat); hipFree(c->d_tri); hipFree(c->d_tri_n);
-    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_prim_idx);
+    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
     c->d_sph = nullptr; c->d_sph_mat = nullptr; c->d_tri = nullptr; c->d_tri_n = nullptr;
-    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_prim_idx = nullptr;
+    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_prim_idx = nullptr; c->d_leaf = nullptr;
     c->has_scene = false;
 }
 static void free_pool(rt_ctx* c) {
     hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.loc);
-    hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.hitlist); hipFree(c->P.occl); hipFree(c->P.scol);
+    hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.occl); hipFree(c->P.scol);
+    hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr); hipFree(c->P.hit_base);
+    hipFree(c->P.child_base); hipFree(c->P.blocksum); hipFree(c->P.hitlist);
     c->P = DPool{};
     c->pool_capacity = c->scol_capacity = c->occl_capacity = 0;
 }
@@ -108,6 +111,8 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     }
     rt_ctx* c = new rt_ctx();
     if (opt) c->opt = *opt;
+    if (const char* e = getenv("RT_PACKET_GENS")) c->packet_gens_extend = atoi(e);
+    if (const char* e = getenv("RT_PACKET_SHADOW_GENS")) c->packet_gens_shadow = atoi(e);
     c->device = c->opt.device;
     if (c->device < 0 || c->device >= ndev) { delete c; rt_set_error("device ordinal out of range"); return RT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(c->device));
@@ -255,9 +260,9 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     // the LBVH is also built when brute force renders, if rt_query_rays may ask for it
     if (S.n_prims >= 2) {
         int root = 0;
-        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &root);
+        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf, &root);
         if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
-        S.nodes = c->d_nodes; S.prim_idx = c->d_prim_idx; S.root = root;
+        S.nodes = c->d_nodes; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = root;
     } else {
         accel = RT_ACCEL_BRUTE;
     }
@@ -320,6 +325,13 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.loc, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.cre, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.cra, capacity * sizeof(float4)));
+    uint64_t groups = capacity / 64 + 2, sblocks = groups / 256 + 2;
+    HIP_TRY(hipMalloc(&c->P.mask_hit, groups * 8));
+    HIP_TRY(hipMalloc(&c->P.mask_refl, groups * 8));
+    HIP_TRY(hipMalloc(&c->P.mask_refr, groups * 8));
+    HIP_TRY(hipMalloc(&c->P.hit_base, groups * 4));
+    HIP_TRY(hipMalloc(&c->P.child_base, groups * 4));
+    HIP_TRY(hipMalloc(&c->P.blocksum, sblocks * sizeof(uint2)));
     HIP_TRY(hipMalloc(&c->P.hitlist, capacity * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->P.occl, occl));
     HIP_TRY(hipMalloc(&c->P.scol, samples * sizeof(float4)));
@@ -331,7 +343,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
 // ---------------------------------------------------------------- batch scheduler
 struct BatchResult {
     bool overflow = false;
-    uint64_t secondary = 0, shadow = 0, nodes[2] = {0, 0}, sph[2] = {0, 0}, tri[2] = {0, 0};
+    uint64_t secondary = 0, shadow = 0, nodes[2] = {0, 0}, sph[2] = {0, 0}, tri[2] = {0, 0}, lane_nodes[2] = {0, 0}, lane_prims[2] = {0, 0};
     int generations = 0;
 };
 
@@ -374,9 +386,17 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     tm.mark(3);
     uint64_t bound = nsamples;
     for (int g = 0; g <= S.max_depth; g++) {
-        rtk_extend(st, c->accel, S, c->P, c->d_counters, g, bound, c->max_blocks);
+        // LBVH: generations whose rays are still coherent walk the tree as wave packets
+        int acc_e = c->accel, acc_s = c->accel;
+        if (c->accel == RT_ACCEL_LBVH) {
+            if (g < c->packet_gens_extend) acc_e = 3;
+            if (g < c->packet_gens_shadow) acc_s = 3;
+        }
+        rtk_extend(st, acc_e, S, c->P, c->d_counters, g, bound, c->max_blocks);
         tm.mark(0);
-        rtk_shadow(st, c->accel, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
+        rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
+        tm.mark(3);
+        rtk_shadow(st, acc_s, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
         tm.mark(1);
         rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
         tm.mark(2);
@@ -399,7 +419,10 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
             res.shadow += (uint64_t)hc.hit_count[g] * (uint64_t)S.nl;
             if (hc.gen_count[g]) res.generations = g + 1;
         }
-        for (int k = 0; k < 2; k++) { res.nodes[k] = hc.nodes[k]; res.sph[k] = hc.sph_tests[k]; res.tri[k] = hc.tri_tests[k]; }
+        for (int k = 0; k < 2; k++) {
+            res.nodes[k] = hc.nodes[k]; res.sph[k] = hc.sph_tests[k]; res.tri[k] = hc.tri_tests[k];
+            res.lane_nodes[k] = hc.lane_nodes[k]; res.lane_prims[k] = hc.lane_prims[k];
+        }
     }
     return RT_OK;
 }
@@ -412,14 +435,15 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     int rc = set_partition(c, rank, world);
     if (rc != RT_OK) return rc;
     const uint32_t spp = (uint32_t)c->cam.spp;
-    uint64_t want_samples = c->opt.batch_samples > 0 ? (uint64_t)c->opt.batch_samples : (4ull << 20);
+    uint64_t want_samples = c->opt.batch_samples > 0 ? (uint64_t)c->opt.batch_samples : (32ull << 20);
+    if (const char* e = getenv("RT_BATCH_SAMPLES")) want_samples = strtoull(e, nullptr, 10);
     uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
     if (per_tile > 0x7FFFFFFFull) { rt_set_error("sample_rate too large for one tile per batch"); return RT_ERR_UNSUPPORTED; }
     uint32_t tiles_per_batch = (uint32_t)std::max<uint64_t>(1, want_samples / per_tile);
     uint32_t total_tiles = (uint32_t)c->tiles.size();
     tiles_per_batch = std::min(tiles_per_batch, std::max(1u, total_tiles));
     uint64_t batch_samples = (uint64_t)tiles_per_batch * per_tile;
-    uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 6 * batch_samples;
+    uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 4 * batch_samples;
     capacity = std::max(capacity, batch_samples);
     rc = ensure_pool(c, capacity, batch_samples);
     if (rc != RT_OK) return rc;
@@ -463,6 +487,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         acc.rays_shadow += br.shadow;
         for (int k = 0; k < 2; k++) {
             acc.nodes_visited[k] += br.nodes[k]; acc.sphere_tests[k] += br.sph[k]; acc.tri_tests[k] += br.tri[k];
+            acc.lane_node_tests[k] += br.lane_nodes[k]; acc.lane_prim_tests[k] += br.lane_prims[k];
         }
         acc.launches_extend += c->S.max_depth + 1;
         acc.launches_shadow += c->S.nl ? c->S.max_depth + 1 : 0;
@@ -557,8 +582,8 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
                              int any_hit, int accel, int32_t* prim_out, float* dist2_out) {
     if (!c || n < 0 || !o || !d || !prim_out) return RT_ERR_INVALID;
     if (!c->has_scene) return RT_ERR_NO_SCENE;
-    if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH) return RT_ERR_INVALID;
-    if (accel == RT_ACCEL_LBVH && !c->S.nodes) { rt_set_error("scene has fewer than 2 primitives: no LBVH"); return RT_ERR_UNSUPPORTED; }
+    if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH && accel != RT_ACCEL_LBVH_PACKET) return RT_ERR_INVALID;
+    if (accel != RT_ACCEL_BRUTE && !c->S.nodes) { rt_set_error("scene has fewer than 2 primitives: no LBVH"); return RT_ERR_UNSUPPORTED; }
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(c->device));
     float *d_o = nullptr, *d_d = nullptr, *d_m = nullptr, *d_d2 = nullptr; int* d_p = nullptr;

@@ -69,6 +69,7 @@ struct DScene {
     // LBVH (valid when nodes != nullptr)
     const float4* nodes;     // [n_internal][4], see rt_lbvh.hip
     const int* prim_idx;     // [ns+nt] sorted primitive ids (sphere i, or ns + triangle i)
+    const float4* leaf;      // [ns+nt][3] primitive records in tree order, see rt_lbvh.hip
     int root;                // root reference
     int n_prims;
 };
@@ -77,17 +78,26 @@ struct DScene {
 // One record per traced ray, all generations of a batch kept until the bottom-up
 // colour resolve.  SoA, 16-byte elements so every access is a coalesced dwordx4.
 struct DPool {
+    // per ray, all generations of the batch
     float4* o;        // origin xyz, w = parent code (bits): gen 0 -> sample index; else parent ray index
     float4* d;        // direction xyz, w = child slot (0 reflection, 1 refraction)
-    float4* hp;       // hit point xyz, w = primitive id (bits)            [valid for hit rays]
-    float4* hn;       // shading normal xyz, w = material id (bits)
     float4* loc;      // local colour rgb, w = pending code (bits): 0 = delivered,
                       //   else (mat << 2 | refl | refr<<1) + 4  (children still to be added)
     float4* cre;      // colour returned by the reflection child
     float4* cra;      // colour returned by the refraction child
-    uint32_t* hitlist;     // per generation: compacted indices of rays that hit
-    uint8_t* occl;         // per generation: [hit slot * nl + light] 1 = in shadow
-    float4* scol;          // per sample colour of the batch
+    // per ray of the CURRENT generation (index = ray - generation start), rewritten every generation
+    float4* hp;       // hit point xyz, w = primitive id (bits)           [hit rays only]
+    float4* hn;       // shading normal xyz, w = material id (bits)
+    // per 64-ray group of the current generation: wave ballots and their prefix sums
+    unsigned long long* mask_hit;    // ray hit something
+    unsigned long long* mask_refl;   // hit spawns a reflection ray
+    unsigned long long* mask_refr;   // hit spawns a refraction ray
+    uint32_t* hit_base;    // hits before the group
+    uint32_t* child_base;  // next-generation rays before the group
+    uint2* blocksum;       // scan scratch: per 256 groups (hits, children)
+    uint32_t* hitlist;     // compacted: h -> ray index within the generation, in ray order
+    uint8_t* occl;    // [h * nl + light] 1 = in shadow
+    float4* scol;     // per sample colour of the batch
     uint32_t capacity;     // rays
 };
 
@@ -101,6 +111,8 @@ struct DCounters {
     unsigned long long nodes[2];
     unsigned long long sph_tests[2];
     unsigned long long tri_tests[2];
+    unsigned long long lane_nodes[2];     // per-lane box-pair tests / primitive tests actually computed
+    unsigned long long lane_prims[2];
 };
 
 // ---------------------------------------------------------------- jitter

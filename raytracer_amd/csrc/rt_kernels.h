@@ -10,6 +10,8 @@ void rtk_generate(hipStream_t st, const DCamera& cam, const DPool& P, const uint
                   uint32_t tile0, uint32_t nsamples, int max_blocks);
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks);
+// prefix sums over the wave masks of generation g: hit list, hit / next-generation counts, child offsets
+void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks);
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
@@ -26,7 +28,7 @@ void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* 
                       const int* j, float* o_out, float* d_out);
 
 // LBVH over spheres + triangles (Morton codes -> radix sort -> Karras hierarchy ->
-// bottom-up refit).  Allocates *nodes ([n_prims-1][4] float4) and *prim_idx
-// ([n_prims]) with hipMalloc; returns a hipError_t as int.  n_prims >= 2.
+// bottom-up refit).  Allocates *nodes ([n_prims-1][4] float4), *prim_idx ([n_prims])
+// and *leaf ([n_prims][3] float4, primitives in tree order) with hipMalloc; returns a hipError_t as int.  n_prims >= 2.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes,
-              int** prim_idx, int* root);
+              int** prim_idx, float4** leaf, int* root);

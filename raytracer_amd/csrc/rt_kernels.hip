@@ -19,6 +19,8 @@
 #include "rt_trace.h"
 #include "rt_kernels.h"
 
+#include <algorithm>
+
 // ---------------------------------------------------------------- small helpers
 __device__ inline uint32_t gen_start(const DCounters* __restrict__ c, int g) {
     uint32_t s = 0;
@@ -31,27 +33,6 @@ __device__ inline uint32_t gen_size(const DCounters* __restrict__ c, int g, uint
     if (start >= capacity) return 0;
     uint32_t room = capacity - start;
     return n < room ? n : room;
-}
-
-// wave64 compaction: every lane of the wave must call this (inactive lanes with
-// want = 0).  Returns this lane's offset inside the wave's allocation and the
-// allocation base obtained with ONE atomic per wave.
-__device__ inline uint32_t wave_alloc(uint32_t* counter, uint32_t want, uint32_t& base) {
-    // prefix sum of `want` (0, 1 or 2) over the wave via two ballots
-    unsigned long long m1 = __ballot(want >= 1);
-    unsigned long long m2 = __ballot(want >= 2);
-    uint32_t lane_lo = __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0);
-    uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), lane_lo);
-    uint32_t lane_lo2 = __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0);
-    off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), lane_lo2);
-    uint32_t total = (uint32_t)(__popcll(m1) + __popcll(m2));
-    uint32_t b = 0;
-    if (total) {
-        if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, total);
-        b = __builtin_amdgcn_readfirstlane(b);
-    }
-    base = b;
-    return off;
 }
 
 __device__ inline void deliver(const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c) {
@@ -69,8 +50,10 @@ __device__ inline void deliver(const DPool& P, int g, uint32_t parent, uint32_t 
 // once per ray.  All threads of the block must call (barriers inside).
 #define BRUTE_CHUNK 768   // float4 slots: 768 spheres or 256 triangles per chunk (12 KB)
 
+// fetch counts (records read: one per lane in the per-lane walk, one per WAVE in
+// the packet walk) and per-lane test counts (arithmetic actually performed)
 struct TraceStats {
-    unsigned long long nodes = 0, sph = 0, tri = 0;
+    uint32_t nodes = 0, sph = 0, tri = 0, lane_nodes = 0, lane_prims = 0;   // per lane, per launch
 };
 
 template <bool ANY>
@@ -93,7 +76,7 @@ __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3
                     if (ANY) { done = true; break; }
                 }
             }
-            ts.sph += n;
+            ts.sph += n; ts.lane_prims += n;
         }
     }
     for (int base = 0; base < S.nt; base += BRUTE_CHUNK / 3) {
@@ -111,7 +94,7 @@ __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3
                     if (ANY) { done = true; break; }
                 }
             }
-            ts.tri += n;
+            ts.tri += n; ts.lane_prims += n;
         }
     }
 }
@@ -140,8 +123,27 @@ __device__ inline bool box_hit(F3 lo, F3 hi, F3 o, F3 inv, float tmax, float& tn
     return tn <= tf * 1.0000005f && tn <= tmax;
 }
 
-#define LBVH_STACK 64
+#define LBVH_STACK 96   // >= deepest possible tree: 63 Morton bits + 32 index tie-break bits
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4f* cv4p;
+
+// exact test of one tree-ordered leaf record (see rt_lbvh.hip: k_leaves)
+__device__ inline bool leaf_test(F3 o, F3 d, double dd, float4 l0, float4 l1, float4 l2, float dmax,
+                                 float& d2, TraceStats& ts) {
+    if (fbits(l2.z) != 0u) {
+        float tf;
+        ts.lane_prims++;
+        return sphere_test(o, d, dd, l0, dmax, d2, tf);
+    }
+    TriHit h;
+    ts.lane_prims++;
+    bool hit = tri_test(o, d, f3(l0.x, l0.y, l0.z), f3(l0.w, l1.x, l1.y), f3(l1.z, l1.w, l2.x), dmax, h);
+    d2 = h.d2;
+    return hit;
+}
+
+// Per-lane while-while traversal with a private stack: every lane walks its own path.
 template <bool ANY>
 __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
                                   float& best_d2, TraceStats& ts) {
@@ -160,7 +162,7 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
         if (cur >= 0) {
             const float4* nd = S.nodes + 4 * (size_t)cur;
             float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            ts.nodes++;
+            ts.nodes++; ts.lane_nodes++;
             float tn0, tn1;
             bool h0 = box_hit(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), o, inv, tmax, tn0);
             bool h1 = box_hit(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), o, inv, tmax, tn1);
@@ -174,22 +176,12 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
             } else if (h0) { cur = c0; continue; }
             else if (h1) { cur = c1; continue; }
         } else {
-            int prim = S.prim_idx[~cur];
-            bool hit = false;
+            const float4* lf = S.leaf + 3 * (size_t)(~cur);
+            float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
+            int prim = (int)fbits(l2.y);
+            if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
             float d2 = 0;
-            if (prim < S.ns) {
-                float tf;
-                ts.sph++;
-                hit = sphere_test(o, d, dd, S.sph[prim], dmax, d2, tf);
-            } else {
-                F3 a, ab, ac;
-                tri_load(S.tri + 3 * (size_t)(prim - S.ns), a, ab, ac);
-                TriHit h;
-                ts.tri++;
-                hit = tri_test(o, d, a, ab, ac, dmax, h);
-                d2 = h.d2;
-            }
-            if (hit) {
+            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, ts)) {
                 if (ANY) { best = prim; best_d2 = d2; return; }
                 if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
                     best = prim;
@@ -203,23 +195,107 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
     }
 }
 
+// Packet traversal: the 64 rays of a wave walk the tree TOGETHER.  The current
+// node is wave-uniform, so node and leaf records come through the scalar data
+// path (one fetch per wave, operands in SGPRs), the traversal stack lives in the
+// lanes of two VGPRs (entry k in lane k, popped with v_readlane), and there is
+// no divergence inside the loop.  A child is entered when ANY lane's ray hits its
+// box; the nearer child by majority vote goes first.  Every lane still applies its
+// own distance bound and the exact tests, so the result per ray is the same as
+// the per-lane walk (and as brute force); only the visiting order is shared.
+// Pays off when the wave's rays are coherent (primary rays of one screen patch,
+// shadow rays towards one light).  All 64 lanes must call.
+template <bool ANY>
+__device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
+                                         float& best_d2, TraceStats& ts) {
+    best = -1;
+    best_d2 = dmax;
+    bool alive = active;
+    if (__ballot(alive) == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const bool lane0 = lane == 0;
+    double dd = (double)dot3(d, d);
+    float ddf = dot3(d, d);
+    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float tmax = (dmax < __builtin_inff()) ? __builtin_sqrtf(dmax / ddf) * 1.00001f : __builtin_inff();
+    // The tree is read-only for the whole launch and the record address is
+    // wave-uniform: reading through the constant address space makes the compiler
+    // fetch a record with scalar loads (s_load_dwordx16) instead of 64 identical
+    // per-lane loads.
+    cv4p nodes = (cv4p)S.nodes;
+    cv4p leaf = (cv4p)S.leaf;
+    int vs0 = 0, vs1 = 0;   // 128-entry wave-shared stack, one entry per lane
+    int sp = 0;
+    int cur = S.root;
+    while (true) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        if (cur >= 0) {
+            cv4p nd = nodes + 4 * (size_t)cur;
+            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            if (lane0) ts.nodes++;
+            if (alive) ts.lane_nodes++;
+            float tn0, tn1;
+            bool h0 = box_hit(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), o, inv, tmax, tn0) && alive;
+            bool h1 = box_hit(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), o, inv, tmax, tn1) && alive;
+            unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+            if (m0 != 0ull && m1 != 0ull) {
+                int v0 = __popcll(__ballot(h0 && (!h1 || tn0 <= tn1)));
+                int v1 = __popcll(__ballot(h1 && (!h0 || tn1 < tn0)));
+                bool swap = v1 > v0;
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                // push: entry sp lives in lane sp & 63 of vs0 / vs1
+                if (sp < 64) vs0 = (lane == sp) ? farc : vs0;
+                else if (sp < 128) vs1 = (lane == sp - 64) ? farc : vs1;
+                sp = (sp < 128) ? sp + 1 : sp;
+                cur = nearc;
+                continue;
+            } else if (m0 != 0ull) { cur = c0; continue; }
+            else if (m1 != 0ull) { cur = c1; continue; }
+        } else {
+            cv4p lf = leaf + 3 * (size_t)(~cur);
+            v4f r0 = lf[0], r1 = lf[1], r2 = lf[2];
+            float4 l0 = make_float4(r0.x, r0.y, r0.z, r0.w), l1 = make_float4(r1.x, r1.y, r1.z, r1.w),
+                   l2 = make_float4(r2.x, r2.y, r2.z, r2.w);
+            int prim = (int)fbits(l2.y);
+            if (lane0) { if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++; }
+            if (alive) {
+                float d2 = 0;
+                if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, ts)) {
+                    if (ANY) { best = prim; best_d2 = d2; alive = false; }
+                    else if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
+                        best = prim;
+                        best_d2 = d2;
+                        tmax = __builtin_sqrtf(d2 / ddf) * 1.00001f;
+                    }
+                }
+            }
+            if (ANY && __ballot(alive) == 0ull) return;
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = (sp < 64) ? __builtin_amdgcn_readlane(vs0, sp) : __builtin_amdgcn_readlane(vs1, sp - 64);
+    }
+}
+
 template <int ACCEL, bool ANY>
 __device__ inline void trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
                              int& best, float& best_d2, TraceStats& ts) {
     if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, ts);
-    else lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, ts);
+    else if (ACCEL == 2) lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, ts);
+    else lbvh_trace_packet<ANY>(S, active, o, d, dmax, best, best_d2, ts);
 }
 
-__device__ inline void flush_stats(DCounters* C, int which, TraceStats ts) {
-    for (int off = 32; off > 0; off >>= 1) {
-        ts.nodes += __shfl_down(ts.nodes, off);
-        ts.sph += __shfl_down(ts.sph, off);
-        ts.tri += __shfl_down(ts.tri, off);
-    }
+__device__ inline void flush_stats(DCounters* C, int which, const TraceStats& ts) {
+    unsigned long long v[5] = {ts.nodes, ts.sph, ts.tri, ts.lane_nodes, ts.lane_prims};
+    for (int k = 0; k < 5; k++)
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
     if ((threadIdx.x & 63) == 0) {
-        if (ts.nodes) atomicAdd(&C->nodes[which], ts.nodes);
-        if (ts.sph) atomicAdd(&C->sph_tests[which], ts.sph);
-        if (ts.tri) atomicAdd(&C->tri_tests[which], ts.tri);
+        if (v[0]) atomicAdd(&C->nodes[which], v[0]);
+        if (v[1]) atomicAdd(&C->sph_tests[which], v[1]);
+        if (v[2]) atomicAdd(&C->tri_tests[which], v[2]);
+        if (v[3]) atomicAdd(&C->lane_nodes[which], v[3]);
+        if (v[4]) atomicAdd(&C->lane_prims[which], v[4]);
     }
 }
 
@@ -287,45 +363,184 @@ __global__ void k_init_counters(DCounters* C, uint32_t nsamples) {
     int i = threadIdx.x;
     if (i <= RT_MAX_GEN) { C->gen_count[i] = (i == 0) ? nsamples : 0; C->hit_count[i] = 0; }
     if (i == 0) { C->overflow = 0; C->pad = 0; }
-    if (i < 2) { C->nodes[i] = 0; C->sph_tests[i] = 0; C->tri_tests[i] = 0; }
+    if (i < 2) { C->nodes[i] = 0; C->sph_tests[i] = 0; C->tri_tests[i] = 0; C->lane_nodes[i] = 0; C->lane_prims[i] = 0; }
+}
+
+// ---------------------------------------------------------------- spawn decision
+// Which secondary rays a hit sends out (src/raytrace.cpp:589, :600-615): reflection
+// iff every specular component is non-zero, refraction iff every transmissive
+// component is non-zero and there is no total internal reflection.  Used by the
+// extend kernel (to size the next generation) and by the shade kernel (to build
+// the rays); same inputs, same arithmetic, same answer.
+struct Spawn {
+    bool refl, refr;
+    double dni, ior, tir;
+};
+__device__ inline Spawn spawn_of(F3 spec, F3 trans, float iorf, F3 direct, F3 normal) {
+    Spawn s;
+    s.refl = (spec.x != 0 && spec.y != 0 && spec.z != 0);
+    s.refr = false;
+    s.dni = 0; s.ior = 0; s.tir = 0;
+    if (trans.x != 0 && trans.y != 0 && trans.z != 0) {
+        F3 irdir = direct * -1.0f;
+        s.dni = (double)dot3(irdir, normal);
+        s.ior = (s.dni <= 0) ? (double)iorf : 1.0 / (double)iorf;
+        s.tir = 1.0 - (s.ior * s.ior) * (1.0 - (s.dni * s.dni));
+        s.refr = s.tir >= 0;
+    }
+    return s;
 }
 
 // ---------------------------------------------------------------- extend (closest hit)
 // evaluateRayTree's intersect + miss branch (src/raytrace.cpp:139-150): a miss
-// returns the background to the parent at once; a hit is recorded and its ray
-// index appended to the generation's compacted hit list.
+// returns the background to the parent at once; a hit leaves its record (point,
+// normal) at the ray's slot.  Queue compaction is wave64 ballots + a prefix sum:
+// each wave publishes three 64-bit masks for its 64 rays -- hit, spawns a
+// reflection ray, spawns a refraction ray -- and the scan kernels below turn the
+// popcounts into the compacted hit list and the write offsets of the next
+// generation.  No atomics: a single hot counter sustains only ~90 returning
+// atomics per microsecond on this chip, which one atomic per wave would exceed
+// many times over; the scan also keeps hits and children in ray order, which
+// preserves the coherence of neighbouring rays.
+// Every lane of the wave must call (ballots inside).
+template <int ACCEL>
+__device__ inline void extend_one(const DScene& S, const DPool& P, int g, uint32_t start, uint32_t count,
+                                  uint32_t i, float4* lds, TraceStats& ts) {
+    bool inrange = i < count;
+    uint32_t r = start + (inrange ? i : 0);
+    float4 qo = P.o[r], qd = P.d[r];
+    uint32_t parent = fbits(qo.w);
+    // generation-0 slots of pixels outside the film carry no ray
+    bool active = inrange && !(g == 0 && parent == 0xFFFFFFFFu);
+    F3 o = f3(qo), d = f3(qd);
+    int best; float best_d2;
+    trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, ts);
+    bool hit = active && best >= 0;
+    bool refl = false, refr = false;
+    if (hit) {
+        F3 point, normal; int mat;
+        make_hit(S, o, d, (double)dot3(d, d), best, __builtin_inff(), point, normal, mat);
+        P.hp[i] = make_float4(point.x, point.y, point.z, bitsf((uint32_t)best));
+        P.hn[i] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat));
+        if (g + 1 <= S.max_depth) {   // deeper children are never traced (src/raytrace.cpp:132-135)
+            const float4* M = S.mats + 4 * (size_t)mat;
+            Spawn sp = spawn_of(f3(M[2]), f3(M[3]), M[1].w, d, normal);
+            refl = sp.refl; refr = sp.refr;
+        }
+    } else if (inrange) {
+        if (active) deliver(P, g, parent, fbits(qd.w), S.bg);
+        P.loc[r] = make_float4(0, 0, 0, 0);   // nothing pending for the resolve pass
+    }
+    unsigned long long mh = __ballot(hit), m1 = __ballot(refl), m2 = __ballot(refr);
+    if ((threadIdx.x & 63) == 0 && inrange) {
+        uint32_t grp = i >> 6;
+        P.mask_hit[grp] = mh; P.mask_refl[grp] = m1; P.mask_refr[grp] = m2;
+    }
+}
+
 template <int ACCEL>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounters* C, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
+    if (C->overflow) return;   // ray slots past an overflow were never written: the host re-runs the batch
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
     TraceStats ts;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
-        uint32_t i = base + threadIdx.x;
-        bool inrange = i < count;
-        uint32_t r = start + (inrange ? i : 0);
-        float4 qo = P.o[r], qd = P.d[r];
-        uint32_t parent = fbits(qo.w);
-        // generation-0 slots of pixels outside the film carry no ray
-        bool active = inrange && !(g == 0 && parent == 0xFFFFFFFFu);
-        F3 o = f3(qo), d = f3(qd);
-        int best; float best_d2;
-        trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, ts);
-        bool hit = active && best >= 0;
-        if (hit) {
-            F3 point, normal; int mat;
-            make_hit(S, o, d, (double)dot3(d, d), best, __builtin_inff(), point, normal, mat);
-            P.hp[r] = make_float4(point.x, point.y, point.z, bitsf((uint32_t)best));
-            P.hn[r] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat));
-        } else if (inrange) {
-            if (active) deliver(P, g, parent, fbits(qd.w), S.bg);
-            P.loc[r] = make_float4(0, 0, 0, 0);   // nothing pending for the resolve pass
-        }
-        uint32_t wbase;
-        uint32_t off = wave_alloc(&C->hit_count[g], hit ? 1u : 0u, wbase);
-        if (hit) P.hitlist[start + wbase + off] = r;
-    }
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
+        extend_one<ACCEL>(S, P, g, start, count, base + threadIdx.x, lds, ts);
     flush_stats(C, 0, ts);
+}
+
+// ---------------------------------------------------------------- queue compaction (prefix sums)
+// One thread per 64-ray group.  scan1: per-block sums of (hits, children);
+// scan2: one block turns the block sums into exclusive prefixes and publishes the
+// generation totals; scan3: per-group bases + the compacted hit list.
+#define SCAN_BLOCK 256
+
+__device__ inline uint2 group_counts(const DPool& P, uint32_t grp, uint32_t ngroups) {
+    if (grp >= ngroups) return make_uint2(0, 0);
+    return make_uint2((uint32_t)__popcll(P.mask_hit[grp]),
+                      (uint32_t)(__popcll(P.mask_refl[grp]) + __popcll(P.mask_refr[grp])));
+}
+
+// block-wide exclusive scan of a uint2 (both components), returns the block total
+__device__ inline uint2 block_scan(uint2 v, uint2* lds /*[SCAN_BLOCK]*/, uint2& total) {
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint2 a = lds[t];
+        uint2 b = (t >= off) ? lds[t - off] : make_uint2(0, 0);
+        __syncthreads();
+        lds[t] = make_uint2(a.x + b.x, a.y + b.y);
+        __syncthreads();
+    }
+    uint2 incl = lds[t];
+    total = lds[SCAN_BLOCK - 1];
+    __syncthreads();
+    return make_uint2(incl.x - v.x, incl.y - v.y);
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(DPool P, DCounters* C, int g) {
+    __shared__ uint2 lds[SCAN_BLOCK];
+    if (C->overflow) return;
+    const uint32_t start = gen_start(C, g);
+    const uint32_t count = gen_size(C, g, start, P.capacity);
+    const uint32_t ngroups = (count + 63) >> 6;
+    const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        uint2 v = group_counts(P, b * SCAN_BLOCK + threadIdx.x, ngroups), total;
+        block_scan(v, lds, total);
+        if (threadIdx.x == 0) P.blocksum[b] = total;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(DPool P, DCounters* C, int g) {
+    __shared__ uint2 lds[SCAN_BLOCK];
+    if (C->overflow) return;
+    const uint32_t start = gen_start(C, g);
+    const uint32_t count = gen_size(C, g, start, P.capacity);
+    const uint32_t ngroups = (count + 63) >> 6;
+    const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    uint2 carry = make_uint2(0, 0);
+    for (uint32_t base = 0; base < nblocks; base += SCAN_BLOCK) {
+        uint32_t b = base + threadIdx.x;
+        uint2 v = (b < nblocks) ? P.blocksum[b] : make_uint2(0, 0), total;
+        uint2 ex = block_scan(v, lds, total);
+        if (b < nblocks) P.blocksum[b] = make_uint2(carry.x + ex.x, carry.y + ex.y);
+        carry = make_uint2(carry.x + total.x, carry.y + total.y);
+    }
+    if (threadIdx.x == 0) {
+        C->hit_count[g] = carry.x;
+        C->gen_count[g + 1] = carry.y;
+        if ((uint64_t)start + C->gen_count[g] + carry.y > (uint64_t)P.capacity) C->overflow = 1;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int g) {
+    __shared__ uint2 lds[SCAN_BLOCK];
+    if (C->overflow) return;
+    const uint32_t start = gen_start(C, g);
+    const uint32_t count = gen_size(C, g, start, P.capacity);
+    const uint32_t ngroups = (count + 63) >> 6;
+    const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        uint32_t grp = b * SCAN_BLOCK + threadIdx.x;
+        uint2 v = group_counts(P, grp, ngroups), total;
+        uint2 ex = block_scan(v, lds, total);
+        if (grp < ngroups) {
+            uint2 bs = P.blocksum[b];
+            uint32_t hbase = bs.x + ex.x;
+            P.hit_base[grp] = hbase;
+            P.child_base[grp] = bs.y + ex.y;
+            unsigned long long m = P.mask_hit[grp];
+            uint32_t first = grp << 6;
+            while (m) {
+                int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                P.hitlist[hbase++] = first + (uint32_t)bit;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- shadow (any hit)
@@ -334,18 +549,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounter
 template <int ACCEL>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounters* C, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
-    const uint32_t start = gen_start(C, g);
+    if (C->overflow) return;
     const uint32_t nh = C->hit_count[g];
     const uint64_t items = (uint64_t)nh * (uint64_t)S.nl;
     TraceStats ts;
-    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items;
-         base += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items; base += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t k = base + threadIdx.x;
         bool active = k < items;
         uint32_t h = active ? (uint32_t)(k / (uint32_t)S.nl) : 0;
         int j = active ? (int)(k - (uint64_t)h * (uint32_t)S.nl) : 0;
-        uint32_t r = P.hitlist[start + h];
-        F3 point = f3(P.hp[r]);
+        F3 point = f3(P.hp[P.hitlist[h]]);
         F3 I; float dist2;
         light_dir(S.lights[j], point, I, dist2);
         int best; float best_d2;
@@ -358,113 +571,96 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounter
 // ---------------------------------------------------------------- shade + spawn
 // getColor (src/raytrace.cpp:488-632) without the recursion: local illumination
 // with the shadow results, then the reflection / refraction rays of the next
-// generation are appended to the pool (or, past max_depth, the background is
-// added directly as evaluateRayTree :132-135 returns it without tracing).
+// generation are written at the offsets the scan assigned (or, past max_depth,
+// the background is added directly as evaluateRayTree :132-135 returns it
+// without tracing).
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters* C, int g) {
+    if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
     const uint32_t next_start = start + C->gen_count[g];
-    for (uint32_t base = blockIdx.x * blockDim.x; base < nh; base += gridDim.x * blockDim.x) {
-        uint32_t h = base + threadIdx.x;
-        bool active = h < nh;
-        uint32_t want = 0;
-        uint32_t r = 0;
-        F3 point = f3(0, 0, 0), rfd = f3(0, 0, 0), rad = f3(0, 0, 0);
-        bool refl = false, refr = false;
-        if (active) {
-            r = P.hitlist[start + h];
-            float4 qd = P.d[r], qp = P.hp[r], qn = P.hn[r];
-            uint32_t parent = fbits(P.o[r].w);
-            F3 direct = f3(qd);
-            point = f3(qp);
-            F3 normal = f3(qn);
-            int mat = (int)fbits(qn.w);
-            const float4* M = S.mats + 4 * (size_t)mat;
-            float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
-            F3 dif = f3(m1), spec = f3(m2), trans = f3(m3);
-            float ns = m0.w, iorf = m1.w;
-            float rval = m0.x, gval = m0.y, bval = m0.z;
-            rval *= S.ambient.x; gval *= S.ambient.y; bval *= S.ambient.z;
-            for (int j = 0; j < S.nl; j++) {
-                const DLight L = S.lights[j];
-                if (P.occl[(uint64_t)h * (uint32_t)S.nl + j]) continue;
-                F3 I; float dist2f;
-                light_dir(L, point, I, dist2f);
-                double dist = (double)dist2f;
-                double dotni = (double)dot3(normal, I);
-                double cosAlpha = (dotni > 0) ? dotni : 0;
-                F3 lc = f3(L.cr, L.cg, L.cb);
-                F3 illum = lc;
-                if (L.type == 2) {
-                    illum = illum * (float)(1.0 / dist);
-                } else if (L.type == 3) {
-                    double alpha = acos(cosAlpha);
-                    if (alpha < (double)L.a1) illum = lc * (float)(1.0 / dist);
-                    else if (alpha > (double)L.a2) illum = f3(0, 0, 0);
-                    else {
-                        double amt = 1 - ((alpha - (double)L.a1) / (double)(L.a2 - L.a1));
-                        illum = lc * (float)((1.0 / dist) * amt);
-                    }
-                }
-                rval = (float)((double)rval + (double)(dif.x * illum.x) * cosAlpha);
-                gval = (float)((double)gval + (double)(dif.y * illum.y) * cosAlpha);
-                bval = (float)((double)bval + (double)(dif.z * illum.z) * cosAlpha);
-                F3 ref = (normal * (float)(2.0 * dotni)) - I;
-                F3 Vv = direct * -1.0f;
-                double powval = (double)dot3(norm3(Vv), norm3(ref));
-                double pspec = (powval < 0.0) ? 0.0 : pow(powval, (double)ns);
-                rval = (float)((double)rval + ((double)spec.x * pspec) * (double)illum.x);
-                gval = (float)((double)gval + ((double)spec.y * pspec) * (double)illum.y);
-                bval = (float)((double)bval + ((double)spec.z * pspec) * (double)illum.z);
-            }
-            F3 irdir = direct * -1.0f;
-            refl = (spec.x != 0 && spec.y != 0 && spec.z != 0);
-            if (refl) rfd = (normal * (2.0f * dot3(normal, irdir))) - irdir;
-            if (trans.x != 0 && trans.y != 0 && trans.z != 0) {
-                double dni = (double)dot3(irdir, normal);
-                double ior = (dni <= 0) ? (double)iorf : 1.0 / (double)iorf;
-                double tir = 1.0 - (ior * ior) * (1.0 - (dni * dni));
-                if (tir >= 0) {
-                    refr = true;
-                    F3 refdir;
-                    if (dni >= 0) refdir = (normal * (float)(ior * dni - __builtin_sqrt(tir))) - (irdir * (float)ior);
-                    else          refdir = (normal * (float)(ior * dni + __builtin_sqrt(tir))) - (irdir * (float)ior);
-                    rad = norm3(refdir);
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x) {
+        const uint32_t i = P.hitlist[h];
+        const uint32_t r = start + i;
+        float4 qd = P.d[r], qp = P.hp[i], qn = P.hn[i];
+        uint32_t parent = fbits(P.o[r].w);
+        F3 direct = f3(qd);
+        F3 point = f3(qp);
+        F3 normal = f3(qn);
+        int mat = (int)fbits(qn.w);
+        const float4* M = S.mats + 4 * (size_t)mat;
+        float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+        F3 dif = f3(m1), spec = f3(m2), trans = f3(m3);
+        float ns = m0.w, iorf = m1.w;
+        float rval = m0.x, gval = m0.y, bval = m0.z;
+        rval *= S.ambient.x; gval *= S.ambient.y; bval *= S.ambient.z;
+        for (int j = 0; j < S.nl; j++) {
+            const DLight L = S.lights[j];
+            if (P.occl[(uint64_t)h * (uint32_t)S.nl + j]) continue;
+            F3 I; float dist2f;
+            light_dir(L, point, I, dist2f);
+            double dist = (double)dist2f;
+            double dotni = (double)dot3(normal, I);
+            double cosAlpha = (dotni > 0) ? dotni : 0;
+            F3 lc = f3(L.cr, L.cg, L.cb);
+            F3 illum = lc;
+            if (L.type == 2) {
+                illum = illum * (float)(1.0 / dist);
+            } else if (L.type == 3) {
+                double alpha = acos(cosAlpha);
+                if (alpha < (double)L.a1) illum = lc * (float)(1.0 / dist);
+                else if (alpha > (double)L.a2) illum = f3(0, 0, 0);
+                else {
+                    double amt = 1 - ((alpha - (double)L.a1) / (double)(L.a2 - L.a1));
+                    illum = lc * (float)((1.0 / dist) * amt);
                 }
             }
-            bool leaf = !(refl || refr);
-            if (!leaf && g + 1 > S.max_depth) {
-                // children sit past max_depth: each returns the background untraced
-                if (refl) { rval += spec.x * S.bg.x; gval += spec.y * S.bg.y; bval += spec.z * S.bg.z; }
-                if (refr) { rval += trans.x * S.bg.x; gval += trans.y * S.bg.y; bval += trans.z * S.bg.z; }
-                leaf = true;
-            }
-            if (leaf) {
-                deliver(P, g, parent, fbits(qd.w), f3(rval, gval, bval));
-                P.loc[r] = make_float4(rval, gval, bval, 0.0f);
-            } else {
-                uint32_t code = 4u + (((uint32_t)mat << 2) | (refl ? 1u : 0u) | (refr ? 2u : 0u));
-                P.loc[r] = make_float4(rval, gval, bval, bitsf(code));
-                want = (refl ? 1u : 0u) + (refr ? 1u : 0u);
-            }
+            rval = (float)((double)rval + (double)(dif.x * illum.x) * cosAlpha);
+            gval = (float)((double)gval + (double)(dif.y * illum.y) * cosAlpha);
+            bval = (float)((double)bval + (double)(dif.z * illum.z) * cosAlpha);
+            F3 ref = (normal * (float)(2.0 * dotni)) - I;
+            F3 Vv = direct * -1.0f;
+            double powval = (double)dot3(norm3(Vv), norm3(ref));
+            double pspec = (powval < 0.0) ? 0.0 : pow(powval, (double)ns);
+            rval = (float)((double)rval + ((double)spec.x * pspec) * (double)illum.x);
+            gval = (float)((double)gval + ((double)spec.y * pspec) * (double)illum.y);
+            bval = (float)((double)bval + ((double)spec.z * pspec) * (double)illum.z);
         }
-        uint32_t wbase;
-        uint32_t off = wave_alloc(&C->gen_count[g + 1], want, wbase);
-        if (want) {
-            uint64_t at = (uint64_t)next_start + wbase + off;
-            if (at + want > (uint64_t)P.capacity) {
-                C->overflow = 1;
-            } else {
-                if (refl) {
-                    P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
-                    P.d[at] = make_float4(rfd.x, rfd.y, rfd.z, bitsf(0u));
-                    at++;
-                }
-                if (refr) {
-                    P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
-                    P.d[at] = make_float4(rad.x, rad.y, rad.z, bitsf(1u));
-                }
-            }
+        F3 irdir = direct * -1.0f;
+        Spawn sp = spawn_of(spec, trans, iorf, direct, normal);
+        bool leaf = !(sp.refl || sp.refr);
+        if (!leaf && g + 1 > S.max_depth) {
+            // children sit past max_depth: each returns the background untraced
+            if (sp.refl) { rval += spec.x * S.bg.x; gval += spec.y * S.bg.y; bval += spec.z * S.bg.z; }
+            if (sp.refr) { rval += trans.x * S.bg.x; gval += trans.y * S.bg.y; bval += trans.z * S.bg.z; }
+            leaf = true;
+        }
+        if (leaf) {
+            deliver(P, g, parent, fbits(qd.w), f3(rval, gval, bval));
+            P.loc[r] = make_float4(rval, gval, bval, 0.0f);
+            continue;
+        }
+        uint32_t code = 4u + (((uint32_t)mat << 2) | (sp.refl ? 1u : 0u) | (sp.refr ? 2u : 0u));
+        P.loc[r] = make_float4(rval, gval, bval, bitsf(code));
+        // where the scan put this ray's children: rays of the group before it first
+        const uint32_t grp = i >> 6;
+        const unsigned long long below = (1ull << (i & 63u)) - 1ull;
+        uint64_t at = (uint64_t)next_start + P.child_base[grp] +
+                      (uint32_t)__popcll(P.mask_refl[grp] & below) + (uint32_t)__popcll(P.mask_refr[grp] & below);
+        if (at + (sp.refl ? 1u : 0u) + (sp.refr ? 1u : 0u) > (uint64_t)P.capacity) continue;   // overflow, flagged by the scan
+        if (sp.refl) {
+            F3 rfd = (normal * (2.0f * dot3(normal, irdir))) - irdir;
+            P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
+            P.d[at] = make_float4(rfd.x, rfd.y, rfd.z, bitsf(0u));
+            at++;
+        }
+        if (sp.refr) {
+            F3 refdir;
+            if (sp.dni >= 0) refdir = (normal * (float)(sp.ior * sp.dni - __builtin_sqrt(sp.tir))) - (irdir * (float)sp.ior);
+            else             refdir = (normal * (float)(sp.ior * sp.dni + __builtin_sqrt(sp.tir))) - (irdir * (float)sp.ior);
+            F3 rad = norm3(refdir);
+            P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
+            P.d[at] = make_float4(rad.x, rad.y, rad.z, bitsf(1u));
         }
     }
 }
@@ -474,6 +670,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters
 // (src/raytrace.cpp:594-596), then refraction (:625-627) -- and returns the sum
 // to the parent.
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounters* C, int g) {
+    if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -589,14 +786,24 @@ void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
                 uint64_t bound, int max_blocks) {
     dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL(k_extend<1>, grid, block, 0, st, S, P, C, g);
-    else hipLaunchKernelGGL(k_extend<2>, grid, block, 0, st, S, P, C, g);
+    else if (accel == 2) hipLaunchKernelGGL(k_extend<2>, grid, block, 0, st, S, P, C, g);
+    else hipLaunchKernelGGL(k_extend<3>, grid, block, 0, st, S, P, C, g);
+}
+void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {
+    uint64_t groups = (bound + 63) / 64;
+    int blocks = (int)std::min<uint64_t>((groups + SCAN_BLOCK - 1) / SCAN_BLOCK, (uint64_t)max_blocks);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_scan1, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SCAN_BLOCK), 0, st, P, C, g);
+    hipLaunchKernelGGL(k_scan3, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g);
 }
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks) {
     if (S.nl == 0) return;
     dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL(k_shadow<1>, grid, block, 0, st, S, P, C, g);
-    else hipLaunchKernelGGL(k_shadow<2>, grid, block, 0, st, S, P, C, g);
+    else if (accel == 2) hipLaunchKernelGGL(k_shadow<2>, grid, block, 0, st, S, P, C, g);
+    else hipLaunchKernelGGL(k_shadow<3>, grid, block, 0, st, S, P, C, g);
 }
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                int max_blocks) {
@@ -622,9 +829,12 @@ void rtk_query(hipStream_t st, int accel, int any_hit, const DScene& S, int64_t 
     if (accel == 1) {
         if (any_hit) hipLaunchKernelGGL((k_query<1, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
         else hipLaunchKernelGGL((k_query<1, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
-    } else {
+    } else if (accel == 2) {
         if (any_hit) hipLaunchKernelGGL((k_query<2, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
         else hipLaunchKernelGGL((k_query<2, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+    } else {
+        if (any_hit) hipLaunchKernelGGL((k_query<3, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+        else hipLaunchKernelGGL((k_query<3, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
     }
 }
 void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* x, const int* y,

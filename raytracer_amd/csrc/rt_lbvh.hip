@@ -177,17 +177,37 @@ __global__ void k_refit(const Box* boxes, const uint32_t* sorted, int n, const i
     }
 }
 
-#define L_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(vals2); return (int)e_; } } while (0)
+// Leaf records in Morton order, so traversal reads a primitive without going
+// through prim_idx: 3 float4 per leaf,
+//   triangle: (a.xyz, ab.x) (ab.yz, ac.xy) (ac.z, prim id, 0, -)
+//   sphere:   (c.xyz, r)    (-)            (-,    prim id, 1, -)
+__global__ void k_leaves(const float4* sph, int ns, const float4* tri, const uint32_t* sorted, int n, float4* leaf) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t p = sorted[j];
+    float4 q0, q1 = make_float4(0, 0, 0, 0), q2;
+    if ((int)p < ns) {
+        q0 = sph[p];
+        q2 = make_float4(0.0f, __uint_as_float(p), __uint_as_float(1u), 0.0f);
+    } else {
+        const float4* t = tri + 3 * (size_t)(p - ns);
+        q0 = t[0]; q1 = t[1];
+        q2 = make_float4(t[2].x, __uint_as_float(p), __uint_as_float(0u), 0.0f);
+    }
+    leaf[3 * (size_t)j] = q0; leaf[3 * (size_t)j + 1] = q1; leaf[3 * (size_t)j + 2] = q2;
+}
+
+#define L_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(vals2); (void)hipFree(leaf); return (int)e_; } } while (0)
 
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
-              int** prim_idx_out, int* root) {
+              int** prim_idx_out, float4** leaf_out, int* root) {
     int n = ns + nt;
-    *nodes_out = nullptr; *prim_idx_out = nullptr; *root = 0;
+    *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *root = 0;
     if (n < 2) return (int)hipErrorInvalidValue;
     Box* boxes = nullptr; uint32_t* scene = nullptr;
     unsigned long long *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;
     int *child = nullptr, *pin = nullptr, *plf = nullptr; uint32_t* flags = nullptr; void* tmp = nullptr;
-    float4* nodes = nullptr;
+    float4* nodes = nullptr; float4* leaf = nullptr;
     auto cleanup = [&]() {
         void* ptrs[] = {boxes, scene, keys, keys2, vals, child, pin, plf, flags, tmp};
         for (void* p : ptrs) (void)hipFree(p);
@@ -201,6 +221,7 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     L_TRY(hipMalloc(&plf, (size_t)n * sizeof(int)));
     L_TRY(hipMalloc(&flags, (size_t)(n - 1) * sizeof(uint32_t)));
     L_TRY(hipMalloc(&nodes, (size_t)(n - 1) * 4 * sizeof(float4)));
+    L_TRY(hipMalloc(&leaf, (size_t)n * 3 * sizeof(float4)));
     uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     L_TRY(hipMemcpyAsync(scene, init, sizeof(init), hipMemcpyHostToDevice, st));
     L_TRY(hipMemsetAsync(flags, 0, (size_t)(n - 1) * sizeof(uint32_t), st));
@@ -213,11 +234,13 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     L_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, st));
     hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, st, keys2, n, child, pin, plf);
     hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, boxes, vals2, n, child, pin, plf, flags, nodes);
+    hipLaunchKernelGGL(k_leaves, dim3(blocks), dim3(256), 0, st, sph, ns, tri, vals2, n, leaf);
     L_TRY(hipGetLastError());
     L_TRY(hipStreamSynchronize(st));
     cleanup();
     *nodes_out = nodes;
     *prim_idx_out = (int*)vals2;   // sorted primitive ids, kept by the caller
+    *leaf_out = leaf;
     *root = 0;
     return (int)hipSuccess;
 }

@@ -77,7 +77,7 @@ def test_primary_rays_and_closest_hits_known_answers(oracle, tracer, kat, key, s
     assert np.array_equal(bits(d), bits(kat[f"ray_{key}_d"]))
     ref_hit = kat[f"hit_{key}"]
     want_prim, want_d2 = oracle.intersect_many(scene, o, d)
-    for accel in (ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH):
+    for accel in (ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
         prim, d2 = tracer.query_rays(o, d, accel=accel)
         assert np.array_equal(prim >= 0, ref_hit[:, 0] != 0)
         assert np.array_equal(prim, want_prim)
@@ -109,16 +109,18 @@ def test_lbvh_equals_brute_force_on_random_rays(tracer, name):
     n = 200_000
     o, d = _random_rays(scene, n, rng)
     pb, db = tracer.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
-    pl, dl = tracer.query_rays(o, d, accel=ra.RT_ACCEL_LBVH)
     assert (pb >= 0).mean() > 0.2, "ray generator barely hits the scene"
-    assert np.array_equal(pb, pl), f"{(pb != pl).sum()} of {n} closest hits differ"
-    assert np.array_equal(bits(db), bits(dl))
+    for accel in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+        pl, dl = tracer.query_rays(o, d, accel=accel)
+        assert np.array_equal(pb, pl), f"accel {accel}: {(pb != pl).sum()} of {n} closest hits differ"
+        assert np.array_equal(bits(db), bits(dl))
     # any-hit with a finite window (the shadow query): same yes/no
     dmax = np.where(rng.random(n) < 0.5, db * rng.uniform(0.5, 1.5, n).astype(np.float32), np.float32(np.inf)).astype(np.float32)
     dmax[~np.isfinite(dmax)] = np.inf
     ab, _ = tracer.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_BRUTE)
-    al, _ = tracer.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_LBVH)
-    assert np.array_equal(ab >= 0, al >= 0)
+    for accel in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+        al, _ = tracer.query_rays(o, d, dmax=dmax, any_hit=True, accel=accel)
+        assert np.array_equal(ab >= 0, al >= 0)
 
 
 def test_query_matches_oracle_on_random_rays(oracle, tracer):
