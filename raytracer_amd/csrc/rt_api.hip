@@ -252,6 +252,7 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     S.bg = f3(s->background[0], s->background[1], s->background[2]);
     S.ambient = f3(s->ambient[0], s->ambient[1], s->ambient[2]);
     S.n_prims = S.ns + S.nt;
+    S.profile = getenv("RT_PROFILE") != nullptr;
     compute_camera(*s, c->cam);
 
     int thr = c->opt.lbvh_threshold > 0 ? c->opt.lbvh_threshold : 64;
@@ -382,7 +383,6 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     const uint64_t cap = c->P.capacity;
     tm.mark(3);
     rtk_init_counters(st, c->d_counters, nsamples);
-    rtk_generate(st, c->cam, c->P, c->d_tiles, tile0, nsamples, c->max_blocks);
     tm.mark(3);
     uint64_t bound = nsamples;
     for (int g = 0; g <= S.max_depth; g++) {
@@ -392,13 +392,13 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
             if (g < c->packet_gens_extend) acc_e = 3;
             if (g < c->packet_gens_shadow) acc_s = 3;
         }
-        rtk_extend(st, acc_e, S, c->P, c->d_counters, g, bound, c->max_blocks);
+        rtk_extend(st, acc_e, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks);
         tm.mark(0);
         rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
         tm.mark(3);
         rtk_shadow(st, acc_s, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
         tm.mark(1);
-        rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
+        rtk_shade(st, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks);
         tm.mark(2);
         bound = std::min<uint64_t>(bound * 2, cap);
     }
@@ -410,6 +410,13 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     res.overflow = hc.overflow != 0;
+    if (S.profile)
+        fprintf(stderr, "[rt profile] batch tiles %u: closest-hit walks %llu steps %llu walk-cycles %llu (%.0f cyc/step, %.1f steps/walk) wave-cycles %llu | any-hit walks %llu steps %llu walk-cycles %llu (%.0f cyc/step)\n",
+                ntiles, hc.prof_walks[0], hc.prof_steps[0], hc.prof_walk_cycles[0],
+                hc.prof_steps[0] ? (double)hc.prof_walk_cycles[0] / hc.prof_steps[0] : 0.0,
+                hc.prof_walks[0] ? (double)hc.prof_steps[0] / hc.prof_walks[0] : 0.0, hc.prof_wave_cycles[0],
+                hc.prof_walks[1], hc.prof_steps[1], hc.prof_walk_cycles[1],
+                hc.prof_steps[1] ? (double)hc.prof_walk_cycles[1] / hc.prof_steps[1] : 0.0);
     uint64_t used = 0;
     for (int g = 0; g <= S.max_depth + 1 && g <= RT_MAX_GEN; g++) used += hc.gen_count[g];
     if (used > cap) res.overflow = true;
@@ -445,6 +452,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     uint64_t batch_samples = (uint64_t)tiles_per_batch * per_tile;
     uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 4 * batch_samples;
     capacity = std::max(capacity, batch_samples);
+    if (c->opt.pool_rays <= 0) capacity = std::max(capacity, c->pool_capacity);   // keep what earlier frames grew
     rc = ensure_pool(c, capacity, batch_samples);
     if (rc != RT_OK) return rc;
 
@@ -469,9 +477,14 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         if (rc != RT_OK) return rc;
         if (br.overflow) {
             acc.retries++;
-            if (n == 1) {
-                // a single tile does not fit: grow the pool
-                uint64_t bigger = c->pool_capacity * 2;
+            // Prefer a bigger pool (it stays for the following batches and frames) to a
+            // smaller batch; split only when the device cannot hold a pool twice as big.
+            uint64_t bigger = c->pool_capacity * 2;
+            size_t free_b = 0, total_b = 0;
+            // (an explicit rt_options.pool_rays is a hard cap: then batches are split)
+            bool can_grow = c->opt.pool_rays <= 0 && bigger < 0xFFFFFFF0ull && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                            (double)bigger * (140.0 + std::max(1, c->S.nl)) < 0.5 * ((double)free_b + (double)c->pool_capacity * 140.0);
+            if (can_grow || n == 1) {
                 rc = ensure_pool(c, bigger, c->scol_capacity);
                 if (rc != RT_OK) return rc;
                 work.push_back({t0, n});

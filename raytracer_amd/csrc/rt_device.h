@@ -72,6 +72,7 @@ struct DScene {
     const float4* leaf;      // [ns+nt][3] primitive records in tree order, see rt_lbvh.hip
     int root;                // root reference
     int n_prims;
+    int profile;             // 1: collect the cycle counters of DCounters (tuning aid)
 };
 
 // ---------------------------------------------------------------- per-batch ray pool
@@ -113,6 +114,8 @@ struct DCounters {
     unsigned long long tri_tests[2];
     unsigned long long lane_nodes[2];     // per-lane box-pair tests / primitive tests actually computed
     unsigned long long lane_prims[2];
+    // tuning aid (RT_PROFILE=1): shader cycles inside packet walks, walk steps, and wave lifetimes
+    unsigned long long prof_walk_cycles[2], prof_steps[2], prof_wave_cycles[2], prof_walks[2];
 };
 
 // ---------------------------------------------------------------- jitter

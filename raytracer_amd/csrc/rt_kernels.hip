@@ -54,6 +54,7 @@ __device__ inline void deliver(const DPool& P, int g, uint32_t parent, uint32_t 
 // the packet walk) and per-lane test counts (arithmetic actually performed)
 struct TraceStats {
     uint32_t nodes = 0, sph = 0, tri = 0, lane_nodes = 0, lane_prims = 0;   // per lane, per launch
+    unsigned long long walk_cycles = 0, steps = 0, walks = 0;                // tuning aid, lane 0 only
 };
 
 template <bool ANY>
@@ -203,20 +204,42 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
 // box; the nearer child by majority vote goes first.  Every lane still applies its
 // own distance bound and the exact tests, so the result per ray is the same as
 // the per-lane walk (and as brute force); only the visiting order is shared.
-// Pays off when the wave's rays are coherent (primary rays of one screen patch,
-// shadow rays towards one light).  All 64 lanes must call.
+// All 64 lanes must call.
+__device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// slab test against a box held in SGPRs; oi = o * inv precomputed per ray.  One
+// fused multiply-add per plane: the box test only has to be conservative (boxes
+// are padded by 1e-4 of their coordinates at build time, far above the rounding
+// of lo*inv - o*inv), it never decides a hit.
+__device__ inline bool box_hit_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, F3 inv,
+                                   F3 oi, float tmax, float& tnear) {
+    float ax = __builtin_fmaf(lox, inv.x, -oi.x), bx = __builtin_fmaf(hix, inv.x, -oi.x);
+    float ay = __builtin_fmaf(loy, inv.y, -oi.y), by = __builtin_fmaf(hiy, inv.y, -oi.y);
+    float az = __builtin_fmaf(loz, inv.z, -oi.z), bz = __builtin_fmaf(hiz, inv.z, -oi.z);
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    tnear = tn;
+    return tn <= tf * 1.0000005f && tn <= tmax;
+}
+
 template <bool ANY>
 __device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
                                          float& best_d2, TraceStats& ts) {
     best = -1;
     best_d2 = dmax;
     bool alive = active;
-    if (__ballot(alive) == 0ull) return;
+    if (ballot64(alive) == 0ull) return;
     const int lane = (int)(threadIdx.x & 63);
-    const bool lane0 = lane == 0;
     double dd = (double)dot3(d, d);
     float ddf = dot3(d, d);
-    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // A zero direction component would make inv infinite and lo*inv - o*inv an
+    // inf - inf; a 1e-20 slope keeps the slab arithmetic finite and means the same
+    // thing for any box of this scene (the ray stays inside or outside that slab).
+    F3 ds = f3(__builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x,
+               __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y,
+               __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z);
+    F3 inv = f3(1.0f / ds.x, 1.0f / ds.y, 1.0f / ds.z);
+    F3 oi = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     float tmax = (dmax < __builtin_inff()) ? __builtin_sqrtf(dmax / ddf) * 1.00001f : __builtin_inff();
     // The tree is read-only for the whole launch and the record address is
     // wave-uniform: reading through the constant address space makes the compiler
@@ -227,21 +250,24 @@ __device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 
     int vs0 = 0, vs1 = 0;   // 128-entry wave-shared stack, one entry per lane
     int sp = 0;
     int cur = S.root;
+    // statistics are kept wave-uniform (scalar registers) and added once at the end
+    uint32_t n_nodes = 0, n_sph = 0, n_tri = 0, n_lane_nodes = 0, n_lane_prims = 0;
+    unsigned long long t0 = S.profile ? __builtin_readcyclecounter() : 0ull;
     while (true) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         if (cur >= 0) {
             cv4p nd = nodes + 4 * (size_t)cur;
             v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            if (lane0) ts.nodes++;
-            if (alive) ts.lane_nodes++;
             float tn0, tn1;
-            bool h0 = box_hit(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), o, inv, tmax, tn0) && alive;
-            bool h1 = box_hit(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), o, inv, tmax, tn1) && alive;
-            unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            bool h0 = box_hit_fma(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oi, tmax, tn0) && alive;
+            bool h1 = box_hit_fma(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oi, tmax, tn1) && alive;
+            unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
+            n_nodes++;
+            n_lane_nodes += (uint32_t)__popcll(ballot64(alive));
             int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
             if (m0 != 0ull && m1 != 0ull) {
-                int v0 = __popcll(__ballot(h0 && (!h1 || tn0 <= tn1)));
-                int v1 = __popcll(__ballot(h1 && (!h0 || tn1 < tn0)));
+                int v0 = __popcll(ballot64(h0 && (!h1 || tn0 <= tn1)));
+                int v1 = __popcll(m1) + __popcll(m0) - __popcll(m0 & m1) - v0;   // the lanes that prefer child 1
                 bool swap = v1 > v0;
                 int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
                 // push: entry sp lives in lane sp & 63 of vs0 / vs1
@@ -258,10 +284,12 @@ __device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 
             float4 l0 = make_float4(r0.x, r0.y, r0.z, r0.w), l1 = make_float4(r1.x, r1.y, r1.z, r1.w),
                    l2 = make_float4(r2.x, r2.y, r2.z, r2.w);
             int prim = (int)fbits(l2.y);
-            if (lane0) { if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++; }
+            if (fbits(l2.z) != 0u) n_sph++; else n_tri++;
+            n_lane_prims += (uint32_t)__popcll(ballot64(alive));
             if (alive) {
                 float d2 = 0;
-                if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, ts)) {
+                TraceStats dummy;
+                if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, dummy)) {
                     if (ANY) { best = prim; best_d2 = d2; alive = false; }
                     else if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
                         best = prim;
@@ -270,11 +298,16 @@ __device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 
                     }
                 }
             }
-            if (ANY && __ballot(alive) == 0ull) return;
+            if (ANY && ballot64(alive) == 0ull) break;
         }
         if (sp == 0) break;
         sp--;
         cur = (sp < 64) ? __builtin_amdgcn_readlane(vs0, sp) : __builtin_amdgcn_readlane(vs1, sp - 64);
+    }
+    if (lane == 0) {
+        ts.nodes += n_nodes; ts.sph += n_sph; ts.tri += n_tri;
+        ts.lane_nodes += n_lane_nodes; ts.lane_prims += n_lane_prims;
+        if (S.profile) { ts.walk_cycles += __builtin_readcyclecounter() - t0; ts.steps += n_nodes + n_sph + n_tri; ts.walks++; }
     }
 }
 
@@ -296,6 +329,10 @@ __device__ inline void flush_stats(DCounters* C, int which, const TraceStats& ts
         if (v[2]) atomicAdd(&C->tri_tests[which], v[2]);
         if (v[3]) atomicAdd(&C->lane_nodes[which], v[3]);
         if (v[4]) atomicAdd(&C->lane_prims[which], v[4]);
+        if (ts.walks) {
+            atomicAdd(&C->prof_walk_cycles[which], ts.walk_cycles); atomicAdd(&C->prof_steps[which], ts.steps);
+            atomicAdd(&C->prof_walks[which], ts.walks);
+        }
     }
 }
 
@@ -334,19 +371,38 @@ __device__ inline void primary_ray(const DCamera& cam, int x, int y, int j, F3& 
     else { o = p; d = cam.dir; }
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, DPool P, const uint32_t* tiles,
-                                                       uint32_t tile0, uint32_t nsamples) {
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nsamples; s += gridDim.x * blockDim.x) {
-        uint32_t lp = s / (uint32_t)cam.spp;
-        int j = (int)(s - lp * (uint32_t)cam.spp);
+// Ray record of slot i of generation g.  Generation 0 is never stored: its rays
+// are recomputed from the sample index wherever they are needed (the extend and
+// shade kernels), which saves writing and re-reading 32 bytes per sample.
+struct RayRec {
+    F3 o, d;
+    uint32_t parent;   // gen 0: sample index; else index of the parent ray
+    uint32_t slot;     // 0 reflection child, 1 refraction child
+    bool valid;        // false for generation-0 slots of pixels outside the film
+};
+struct GenSrc {        // what generation 0 is generated from
+    DCamera cam;
+    const uint32_t* tiles;
+    uint32_t tile0;
+};
+__device__ inline RayRec load_ray(const DPool& P, const GenSrc& G, int g, uint32_t i, uint32_t r) {
+    RayRec R;
+    if (g == 0) {
+        uint32_t lp = i / (uint32_t)G.cam.spp;
+        int j = (int)(i - lp * (uint32_t)G.cam.spp);
         int x, y, px, py; uint32_t tile;
-        pixel_of(tiles, tile0, lp, x, y, px, py, tile);
-        bool valid = x < cam.width && y < cam.height;
-        F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
-        if (valid) primary_ray(cam, x, y, j, o, d);
-        P.o[s] = make_float4(o.x, o.y, o.z, bitsf(valid ? s : 0xFFFFFFFFu));
-        P.d[s] = make_float4(d.x, d.y, d.z, 0.0f);
+        pixel_of(G.tiles, G.tile0, lp, x, y, px, py, tile);
+        R.valid = x < G.cam.width && y < G.cam.height;
+        R.o = f3(0, 0, 0); R.d = f3(0, 0, 1);
+        if (R.valid) primary_ray(G.cam, x, y, j, R.o, R.d);
+        R.parent = i; R.slot = 0;
+    } else {
+        float4 qo = P.o[r], qd = P.d[r];
+        R.o = f3(qo); R.d = f3(qd);
+        R.parent = fbits(qo.w); R.slot = fbits(qd.w);
+        R.valid = true;
     }
+    return R;
 }
 
 __global__ void k_primary_rays(DCamera cam, int64_t n, const int* x, const int* y, const int* j,
@@ -363,7 +419,10 @@ __global__ void k_init_counters(DCounters* C, uint32_t nsamples) {
     int i = threadIdx.x;
     if (i <= RT_MAX_GEN) { C->gen_count[i] = (i == 0) ? nsamples : 0; C->hit_count[i] = 0; }
     if (i == 0) { C->overflow = 0; C->pad = 0; }
-    if (i < 2) { C->nodes[i] = 0; C->sph_tests[i] = 0; C->tri_tests[i] = 0; C->lane_nodes[i] = 0; C->lane_prims[i] = 0; }
+    if (i < 2) {
+        C->nodes[i] = 0; C->sph_tests[i] = 0; C->tri_tests[i] = 0; C->lane_nodes[i] = 0; C->lane_prims[i] = 0;
+        C->prof_walk_cycles[i] = 0; C->prof_steps[i] = 0; C->prof_wave_cycles[i] = 0; C->prof_walks[i] = 0;
+    }
 }
 
 // ---------------------------------------------------------------- spawn decision
@@ -404,15 +463,13 @@ __device__ inline Spawn spawn_of(F3 spec, F3 trans, float iorf, F3 direct, F3 no
 // preserves the coherence of neighbouring rays.
 // Every lane of the wave must call (ballots inside).
 template <int ACCEL>
-__device__ inline void extend_one(const DScene& S, const DPool& P, int g, uint32_t start, uint32_t count,
-                                  uint32_t i, float4* lds, TraceStats& ts) {
+__device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
+                                  uint32_t count, uint32_t i, float4* lds, TraceStats& ts) {
     bool inrange = i < count;
     uint32_t r = start + (inrange ? i : 0);
-    float4 qo = P.o[r], qd = P.d[r];
-    uint32_t parent = fbits(qo.w);
-    // generation-0 slots of pixels outside the film carry no ray
-    bool active = inrange && !(g == 0 && parent == 0xFFFFFFFFu);
-    F3 o = f3(qo), d = f3(qd);
+    RayRec R = load_ray(P, G, g, inrange ? i : 0, r);
+    bool active = inrange && R.valid;
+    F3 o = R.o, d = R.d;
     int best; float best_d2;
     trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, ts);
     bool hit = active && best >= 0;
@@ -428,7 +485,7 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, int g, uint32
             refl = sp.refl; refr = sp.refr;
         }
     } else if (inrange) {
-        if (active) deliver(P, g, parent, fbits(qd.w), S.bg);
+        if (active) deliver(P, g, R.parent, R.slot, S.bg);
         P.loc[r] = make_float4(0, 0, 0, 0);   // nothing pending for the resolve pass
     }
     unsigned long long mh = __ballot(hit), m1 = __ballot(refl), m2 = __ballot(refr);
@@ -439,14 +496,16 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, int g, uint32
 }
 
 template <int ACCEL>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounters* C, int g) {
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
     if (C->overflow) return;   // ray slots past an overflow were never written: the host re-runs the batch
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
     TraceStats ts;
+    unsigned long long tw = S.profile ? __builtin_readcyclecounter() : 0ull;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
-        extend_one<ACCEL>(S, P, g, start, count, base + threadIdx.x, lds, ts);
+        extend_one<ACCEL>(S, P, G, g, start, count, base + threadIdx.x, lds, ts);
+    if (S.profile && (threadIdx.x & 63) == 0) atomicAdd(&C->prof_wave_cycles[0], __builtin_readcyclecounter() - tw);
     flush_stats(C, 0, ts);
 }
 
@@ -518,6 +577,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(DPool P, DCounters* C, int
 
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int g) {
     __shared__ uint2 lds[SCAN_BLOCK];
+    __shared__ uint32_t hb[SCAN_BLOCK];
+    __shared__ unsigned long long hm[SCAN_BLOCK];
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
@@ -527,19 +588,23 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int
         uint32_t grp = b * SCAN_BLOCK + threadIdx.x;
         uint2 v = group_counts(P, grp, ngroups), total;
         uint2 ex = block_scan(v, lds, total);
+        uint2 bs = P.blocksum[b];
+        uint32_t hbase = bs.x + ex.x;
         if (grp < ngroups) {
-            uint2 bs = P.blocksum[b];
-            uint32_t hbase = bs.x + ex.x;
             P.hit_base[grp] = hbase;
             P.child_base[grp] = bs.y + ex.y;
-            unsigned long long m = P.mask_hit[grp];
-            uint32_t first = grp << 6;
-            while (m) {
-                int bit = __builtin_ctzll(m);
-                m &= m - 1;
-                P.hitlist[hbase++] = first + (uint32_t)bit;
-            }
         }
+        hb[threadIdx.x] = hbase;
+        hm[threadIdx.x] = (grp < ngroups) ? P.mask_hit[grp] : 0ull;
+        __syncthreads();
+        // compacted hit list of the block's 256 groups: one thread per ray, coalesced
+        for (uint32_t k = threadIdx.x; k < SCAN_BLOCK * 64u; k += SCAN_BLOCK) {
+            uint32_t gl = k >> 6, bit = k & 63u;
+            unsigned long long m = hm[gl];
+            if ((m >> bit) & 1ull)
+                P.hitlist[hb[gl] + (uint32_t)__popcll(m & ((1ull << bit) - 1ull))] = ((b * SCAN_BLOCK + gl) << 6) + bit;
+        }
+        __syncthreads();
     }
 }
 
@@ -574,7 +639,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounter
 // generation are written at the offsets the scan assigned (or, past max_depth,
 // the background is added directly as evaluateRayTree :132-135 returns it
 // without tracing).
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters* C, int g) {
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
@@ -582,9 +647,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x) {
         const uint32_t i = P.hitlist[h];
         const uint32_t r = start + i;
-        float4 qd = P.d[r], qp = P.hp[i], qn = P.hn[i];
-        uint32_t parent = fbits(P.o[r].w);
-        F3 direct = f3(qd);
+        float4 qp = P.hp[i], qn = P.hn[i];
+        RayRec R = load_ray(P, G, g, i, r);
+        uint32_t parent = R.parent;
+        F3 direct = R.d;
         F3 point = f3(qp);
         F3 normal = f3(qn);
         int mat = (int)fbits(qn.w);
@@ -636,7 +702,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters
             leaf = true;
         }
         if (leaf) {
-            deliver(P, g, parent, fbits(qd.w), f3(rval, gval, bval));
+            deliver(P, g, parent, R.slot, f3(rval, gval, bval));
             P.loc[r] = make_float4(rval, gval, bval, 0.0f);
             continue;
         }
@@ -689,7 +755,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounte
             float4 t = M[3], c = P.cra[r];
             rval += t.x * c.x; gval += t.y * c.y; bval += t.z * c.z;
         }
-        deliver(P, g, fbits(P.o[r].w), fbits(P.d[r].w), f3(rval, gval, bval));
+        if (g == 0) deliver(P, 0, r, 0, f3(rval, gval, bval));
+        else deliver(P, g, fbits(P.o[r].w), fbits(P.d[r].w), f3(rval, gval, bval));
     }
 }
 
@@ -777,17 +844,29 @@ static inline int grid_for(uint64_t items, int max_blocks) {
 void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples) {
     hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(128), 0, st, C, nsamples);
 }
-void rtk_generate(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles,
-                  uint32_t tile0, uint32_t nsamples, int max_blocks) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(nsamples, max_blocks)), dim3(RT_BLOCK), 0, st, cam, P,
-                       tiles, tile0, nsamples);
+// Traversal launches are persistent grids sized to what is RESIDENT at once: with
+// more blocks than fit, the surplus waves start late and run alone at the end of
+// the launch (each wave owns a fixed share of the rays), which costs more than it
+// hides.  Blocks per CU come from the occupancy query, once per kernel.
+template <typename K>
+static int resident_blocks(K kernel, int max_blocks) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RT_BLOCK, 0) != hipSuccess || per_cu < 1) return max_blocks;
+    int cus = max_blocks / 8;   // max_blocks is 8 x CU count
+    return std::min(max_blocks, std::max(1, per_cu) * cus);
 }
-void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
-                uint64_t bound, int max_blocks) {
-    dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
-    if (accel == 1) hipLaunchKernelGGL(k_extend<1>, grid, block, 0, st, S, P, C, g);
-    else if (accel == 2) hipLaunchKernelGGL(k_extend<2>, grid, block, 0, st, S, P, C, g);
-    else hipLaunchKernelGGL(k_extend<3>, grid, block, 0, st, S, P, C, g);
+
+void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
+                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks) {
+    GenSrc G{cam, tiles, tile0};
+    static int res[4] = {0, 0, 0, 0};
+    if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_extend<1>, max_blocks)
+                                 : accel == 2 ? resident_blocks(k_extend<2>, max_blocks)
+                                              : resident_blocks(k_extend<3>, max_blocks);
+    dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
+    if (accel == 1) hipLaunchKernelGGL(k_extend<1>, grid, block, 0, st, S, P, C, G, g);
+    else if (accel == 2) hipLaunchKernelGGL(k_extend<2>, grid, block, 0, st, S, P, C, G, g);
+    else hipLaunchKernelGGL(k_extend<3>, grid, block, 0, st, S, P, C, G, g);
 }
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {
     uint64_t groups = (bound + 63) / 64;
@@ -800,14 +879,19 @@ void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t b
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks) {
     if (S.nl == 0) return;
-    dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
+    static int res[4] = {0, 0, 0, 0};
+    if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_shadow<1>, max_blocks)
+                                 : accel == 2 ? resident_blocks(k_shadow<2>, max_blocks)
+                                              : resident_blocks(k_shadow<3>, max_blocks);
+    dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL(k_shadow<1>, grid, block, 0, st, S, P, C, g);
     else if (accel == 2) hipLaunchKernelGGL(k_shadow<2>, grid, block, 0, st, S, P, C, g);
     else hipLaunchKernelGGL(k_shadow<3>, grid, block, 0, st, S, P, C, g);
 }
-void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
-               int max_blocks) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
+void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
+               const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks) {
+    GenSrc G{cam, tiles, tile0};
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, G, g);
 }
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks) {
