@@ -58,7 +58,11 @@ struct rt_ctx {
     // scene
     bool has_scene = false;
     int accel = RT_ACCEL_BRUTE;
-    int packet_gens_extend = RT_MAX_GEN, packet_gens_shadow = RT_MAX_GEN;   // see run_batch
+    // LBVH walk per generation: 2 = per-lane, 3 = wave packet.  Chosen by calibrate() from
+    // measured kernel times on a sample of the frame (coherent rays favour the packet walk,
+    // incoherent ones the per-lane walk); RT_PACKET_GENS / RT_PACKET_SHADOW_GENS force it.
+    int8_t mode_extend[RT_MAX_GEN + 1], mode_shadow[RT_MAX_GEN + 1];
+    bool tuned = false, forced_modes = false;
     DScene S{};
     DCamera cam{};
     float4* d_sph = nullptr; int* d_sph_mat = nullptr;
@@ -111,8 +115,15 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     }
     rt_ctx* c = new rt_ctx();
     if (opt) c->opt = *opt;
-    if (const char* e = getenv("RT_PACKET_GENS")) c->packet_gens_extend = atoi(e);
-    if (const char* e = getenv("RT_PACKET_SHADOW_GENS")) c->packet_gens_shadow = atoi(e);
+    for (int g = 0; g <= RT_MAX_GEN; g++) { c->mode_extend[g] = 3; c->mode_shadow[g] = 3; }
+    if (const char* e = getenv("RT_PACKET_GENS")) {
+        c->forced_modes = true;
+        for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_extend[g] = g < atoi(e) ? 3 : 2;
+    }
+    if (const char* e = getenv("RT_PACKET_SHADOW_GENS")) {
+        c->forced_modes = true;
+        for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_shadow[g] = g < atoi(e) ? 3 : 2;
+    }
     c->device = c->opt.device;
     if (c->device < 0 || c->device >= ndev) { delete c; rt_set_error("device ordinal out of range"); return RT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(c->device));
@@ -268,6 +279,7 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
         accel = RT_ACCEL_BRUTE;
     }
     c->accel = accel;
+    c->tuned = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_scene = true;
     return RT_OK;
@@ -388,10 +400,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     for (int g = 0; g <= S.max_depth; g++) {
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
-        if (c->accel == RT_ACCEL_LBVH) {
-            if (g < c->packet_gens_extend) acc_e = 3;
-            if (g < c->packet_gens_shadow) acc_s = 3;
-        }
+        if (c->accel == RT_ACCEL_LBVH) { acc_e = c->mode_extend[g]; acc_s = c->mode_shadow[g]; }
         rtk_extend(st, acc_e, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks);
         tm.mark(0);
         rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
@@ -434,6 +443,80 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     return RT_OK;
 }
 
+// Picks, per ray generation, the faster of the two LBVH walks for the extend and the
+// shadow kernel by timing both on a sample of the frame: as many tiles as one batch holds,
+// evenly spaced over the rank's share of the film, all their samples.  Both walks give
+// bit-identical results, so only speed is at stake; the sample's pixels are discarded.
+// The sample is a whole batch on purpose: a small one measures latency, not throughput,
+// and picks the per-lane walk where the packet walk wins at scale.  Once per loaded scene.
+static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
+    c->tuned = true;
+    if (c->accel != RT_ACCEL_LBVH || c->forced_modes || c->tiles.empty()) return RT_OK;
+    const DScene& S = c->S;
+    const uint32_t spp = (uint32_t)c->cam.spp;
+    const uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
+    const uint32_t total = (uint32_t)c->tiles.size();
+    const int G = S.max_depth + 1;
+    std::vector<hipEvent_t> ev((size_t)G * 4);
+    for (auto& e : ev) hipEventCreate(&e);
+    uint32_t* d_pick = nullptr;
+    float te[4][RT_MAX_GEN + 1] = {}, tsh[4][RT_MAX_GEN + 1] = {};
+    bool ok = false;
+    uint32_t n = std::min(total, std::max(1u, tiles_per_batch));
+    for (; !ok && n >= 1; n /= 2) {
+        std::vector<uint32_t> pick(n);
+        for (uint32_t k = 0; k < n; k++) pick[k] = c->tiles[(uint64_t)k * total / n];
+        hipFree(d_pick); d_pick = nullptr;
+        HIP_TRY(hipMalloc(&d_pick, n * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(d_pick, pick.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        const uint32_t nsamples = (uint32_t)(n * per_tile);
+        ok = true;
+        for (int mode = 2; mode <= 3 && ok; mode++) {
+            hipStream_t st = c->stream;
+            rtk_init_counters(st, c->d_counters, nsamples);
+            uint64_t bound = nsamples;
+            for (int g = 0; g < G; g++) {
+                hipEventRecord(ev[4 * g + 0], st);
+                rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks);
+                hipEventRecord(ev[4 * g + 1], st);
+                rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
+                hipEventRecord(ev[4 * g + 2], st);
+                rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
+                hipEventRecord(ev[4 * g + 3], st);
+                rtk_shade(st, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks);
+                bound = std::min<uint64_t>(bound * 2, c->P.capacity);
+            }
+            DCounters hc;
+            if (hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { ok = false; n = 0; break; }
+            if (hc.overflow) { ok = false; break; }      // sample does not fit the pool: halve it
+            for (int g = 0; g < G; g++) {
+                hipEventElapsedTime(&te[mode][g], ev[4 * g + 0], ev[4 * g + 1]);
+                hipEventElapsedTime(&tsh[mode][g], ev[4 * g + 2], ev[4 * g + 3]);
+            }
+        }
+        if (ok) break;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    hipFree(d_pick);
+    if (ok) {
+        for (int g = 0; g < G; g++) {
+            c->mode_extend[g] = te[3][g] <= te[2][g] ? 3 : 2;
+            c->mode_shadow[g] = tsh[3][g] <= tsh[2][g] ? 3 : 2;
+        }
+        if (getenv("RT_VERBOSE")) {
+            fprintf(stderr, "[rt calibrate] %u tiles; extend (lane/packet ms):", n);
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, te[2][g], te[3][g], c->mode_extend[g] == 3 ? 'P' : 'L');
+            fprintf(stderr, "; shadow:");
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, tsh[2][g], tsh[3][g], c->mode_shadow[g] == 3 ? 'P' : 'L');
+            fprintf(stderr, "\n");
+        }
+    } else if (getenv("RT_VERBOSE")) {
+        fprintf(stderr, "[rt calibrate] no sample fitted the ray pool: keeping the packet walk everywhere\n");
+    }
+    return RT_OK;
+}
+
 static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8_t* d_out, float* d_outf,
                            rt_stats* stats) {
     if (!c) return RT_ERR_INVALID;
@@ -455,6 +538,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     if (c->opt.pool_rays <= 0) capacity = std::max(capacity, c->pool_capacity);   // keep what earlier frames grew
     rc = ensure_pool(c, capacity, batch_samples);
     if (rc != RT_OK) return rc;
+    if (!c->tuned && (rc = calibrate(c, tiles_per_batch)) != RT_OK) return rc;
 
     StageTimes tm;
     tm.st = c->stream;

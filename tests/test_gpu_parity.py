@@ -179,6 +179,32 @@ def test_sharded_render_is_byte_identical_for_any_world_size(tracer, world):
     assert np.array_equal(rd.assemble_host(allsh.cpu().numpy(), world, scene.width, scene.height), full)
 
 
+def test_synthetic_scene_small_scale_against_oracle(oracle, tracer):
+    """BASELINE config 5 at 1/1000 scale (10^3 spheres + 10^4 triangles): LBVH render vs the oracle."""
+    from raytracer_amd.synth import synthetic_scene
+    scene = synthetic_scene(scale=0.001, width=160, height=90, spp=2)
+    tracer.load_scene(scene)
+    rgb, rgbf, st = tracer.render(want_float=True)
+    assert st.accel_used == ra.RT_ACCEL_LBVH
+    orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
+    check_image(rgb, rgbf, orgb, orgbf, "synthetic 0.001")
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow)
+
+
+def test_synthetic_scene_lbvh_equals_brute_force(tracer):
+    """1/100 scale (10^4 spheres + 10^5 triangles): every walk of the tree finds the brute-force hit."""
+    from raytracer_amd.synth import synthetic_scene
+    scene = synthetic_scene(scale=0.01, width=64, height=36, spp=1)
+    tracer.load_scene(scene)
+    o, d = _random_rays(scene, 20_000, np.random.default_rng(11))
+    pb, db = tracer.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
+    assert (pb >= 0).mean() > 0.2
+    for accel in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+        pl, dl = tracer.query_rays(o, d, accel=accel)
+        assert np.array_equal(pb, pl), f"accel {accel}: {(pb != pl).sum()} closest hits differ"
+        assert np.array_equal(bits(db), bits(dl))
+
+
 def test_edge_cases(tracer):
     # empty scene: background everywhere, no secondary or shadow rays
     s = ra.SceneArrays(width=70, height=33, background=np.array([.25, .5, 1], np.float32))
