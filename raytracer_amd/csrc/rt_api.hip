@@ -99,7 +99,7 @@ static void free_pool(rt_ctx* c) {
     hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.loc);
     hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.occl); hipFree(c->P.scol);
     hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr); hipFree(c->P.hit_base);
-    hipFree(c->P.child_base); hipFree(c->P.blocksum); hipFree(c->P.hitlist);
+    hipFree(c->P.child_base); hipFree(c->P.blocksum); hipFree(c->P.hitlist); hipFree(c->P.wq);
     c->P = DPool{};
     c->pool_capacity = c->scol_capacity = c->occl_capacity = 0;
 }
@@ -348,6 +348,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.hitlist, capacity * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->P.occl, occl));
     HIP_TRY(hipMalloc(&c->P.scol, samples * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.wq, (size_t)2 * (RT_MAX_GEN + 1) * RT_WQ_LAUNCH * sizeof(uint32_t)));
     c->P.capacity = (uint32_t)capacity;
     c->pool_capacity = capacity; c->scol_capacity = samples; c->occl_capacity = occl;
     return RT_OK;
@@ -394,7 +395,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     hipStream_t st = c->stream;
     const uint64_t cap = c->P.capacity;
     tm.mark(3);
-    rtk_init_counters(st, c->d_counters, nsamples);
+    rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1);
     tm.mark(3);
     uint64_t bound = nsamples;
     for (int g = 0; g <= S.max_depth; g++) {
@@ -473,7 +474,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         ok = true;
         for (int mode = 2; mode <= 3 && ok; mode++) {
             hipStream_t st = c->stream;
-            rtk_init_counters(st, c->d_counters, nsamples);
+            rtk_init_counters(st, c->d_counters, nsamples, c->P, G);
             uint64_t bound = nsamples;
             for (int g = 0; g < G; g++) {
                 hipEventRecord(ev[4 * g + 0], st);

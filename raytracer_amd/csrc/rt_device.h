@@ -78,8 +78,17 @@ struct DScene {
 // ---------------------------------------------------------------- per-batch ray pool
 // One record per traced ray, all generations of a batch kept until the bottom-up
 // colour resolve.  SoA, 16-byte elements so every access is a coalesced dwordx4.
+// Work distribution of the traversal kernels: RT_NQ counters per launch, each on a cache
+// line of its own (a line sustains only ~90 returning atomics per microsecond), queue q
+// handing out the 64-ray groups q, q + RT_NQ, q + 2 RT_NQ, ...
+#define RT_NQ 256
+#define RT_WQ_STRIDE 32                                  // uint32 per counter = 128 bytes
+#define RT_WQ_LAUNCH (RT_NQ * RT_WQ_STRIDE)              // uint32 per launch
+#define RT_WQ_PROBES 8                                   // neighbours tried once the home queue is empty
+
 struct DPool {
     // per ray, all generations of the batch
+    uint32_t* wq;     // work-queue counters: launch slot 2g (extend of generation g), 2g+1 (shadow); zeroed per batch
     float4* o;        // origin xyz, w = parent code (bits): gen 0 -> sample index; else parent ray index
     float4* d;        // direction xyz, w = child slot (0 reflection, 1 refraction)
     float4* loc;      // local colour rgb, w = pending code (bits): 0 = delivered,

@@ -35,6 +35,39 @@ __device__ inline uint32_t gen_size(const DCounters* __restrict__ c, int g, uint
     return n < room ? n : room;
 }
 
+// Dynamic distribution of 64-item groups over the waves of a persistent grid.  A static
+// stride leaves waves with cheap rays (sky) idle while the ones that drew expensive rays
+// finish: measured, the average wave of the closest-hit kernel was alive for only 65 % of
+// the launch.  Here every wave draws the next group of its home queue with one atomic
+// (issued BEFORE the current group is processed, so its latency is hidden), and once
+// the home queue is empty it helps RT_WQ_PROBES neighbours.  The group a wave processes
+// only selects WHICH rays it works on; results land at positions fixed by the ray index.
+__device__ inline uint32_t wq_grab(uint32_t* counter, uint32_t lane) {
+    uint32_t k = 0;
+    if (lane == 0) k = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return k;
+}
+template <class F>
+__device__ inline void for_each_group(uint32_t* wq, uint64_t ngroups, F&& body) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t q = wave % RT_NQ;
+    int probes = 0;
+    uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
+    while (true) {
+        uint64_t grp = (uint64_t)k * RT_NQ + q;
+        if (grp >= ngroups) {
+            if (++probes > RT_WQ_PROBES) break;
+            q = (q + 1) % RT_NQ;
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
+            continue;
+        }
+        uint32_t kn = wq_grab(wq + q * RT_WQ_STRIDE, lane);     // next group, in flight during body()
+        body(grp);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)kn);
+    }
+}
+
 __device__ inline void deliver(const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c) {
     float4 v = make_float4(c.x, c.y, c.z, 0.0f);
     if (g == 0) P.scol[parent] = v;
@@ -503,8 +536,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounter
     const uint32_t count = gen_size(C, g, start, P.capacity);
     TraceStats ts;
     unsigned long long tw = S.profile ? __builtin_readcyclecounter() : 0ull;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
-        extend_one<ACCEL>(S, P, G, g, start, count, base + threadIdx.x, lds, ts);
+    if (ACCEL == 1) {   // block-wide LDS staging: the whole block moves together
+        for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
+            extend_one<ACCEL>(S, P, G, g, start, count, base + threadIdx.x, lds, ts);
+    } else {
+        for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + 63) >> 6, [&](uint64_t grp) {
+            extend_one<ACCEL>(S, P, G, g, start, count, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
+        });
+    }
     if (S.profile && (threadIdx.x & 63) == 0) atomicAdd(&C->prof_wave_cycles[0], __builtin_readcyclecounter() - tw);
     flush_stats(C, 0, ts);
 }
@@ -618,8 +657,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounter
     const uint32_t nh = C->hit_count[g];
     const uint64_t items = (uint64_t)nh * (uint64_t)S.nl;
     TraceStats ts;
-    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items; base += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t k = base + threadIdx.x;
+    auto one = [&](uint64_t k) {
         bool active = k < items;
         uint32_t h = active ? (uint32_t)(k / (uint32_t)S.nl) : 0;
         int j = active ? (int)(k - (uint64_t)h * (uint32_t)S.nl) : 0;
@@ -629,6 +667,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounter
         int best; float best_d2;
         trace<ACCEL, true>(S, lds, active, point, I, dist2, best, best_d2, ts);
         if (active) P.occl[k] = (best >= 0) ? 1 : 0;
+    };
+    if (ACCEL == 1) {
+        for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items; base += (uint64_t)gridDim.x * blockDim.x)
+            one(base + threadIdx.x);
+    } else {
+        for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + 63) >> 6,
+                       [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });
     }
     flush_stats(C, 1, ts);
 }
@@ -841,7 +886,8 @@ static inline int grid_for(uint64_t items, int max_blocks) {
     return (int)b;
 }
 
-void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples) {
+void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations) {
+    hipMemsetAsync(P.wq, 0, (size_t)2 * generations * RT_WQ_LAUNCH * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(128), 0, st, C, nsamples);
 }
 // Traversal launches are persistent grids sized to what is RESIDENT at once: with

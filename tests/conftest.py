@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch ships its own HIP runtime: import it before the tracer library is loaded so that one
+# process never ends up with the runtime copies initialised in the other order (torch then
+# reports "No HIP GPUs are available" when a test allocates its first tensor).
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
