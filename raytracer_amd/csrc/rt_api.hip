@@ -272,7 +272,7 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     // the LBVH is also built when brute force renders, if rt_query_rays may ask for it
     if (S.n_prims >= 2) {
         int root = 0;
-        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf, &root);
+        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf, &root, &S.depth);
         if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
         S.nodes = c->d_nodes; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = root;
     } else {

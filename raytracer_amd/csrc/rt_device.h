@@ -71,6 +71,7 @@ struct DScene {
     const int* prim_idx;     // [ns+nt] sorted primitive ids (sphere i, or ns + triangle i)
     const float4* leaf;      // [ns+nt][3] primitive records in tree order, see rt_lbvh.hip
     int root;                // root reference
+    int depth;               // most inner nodes above any leaf (bounds the traversal stacks)
     int n_prims;
     int profile;             // 1: collect the cycle counters of DCounters (tuning aid)
 };

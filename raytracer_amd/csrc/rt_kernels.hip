@@ -18,6 +18,13 @@
 // strides over it, so a whole batch is enqueued asynchronously.
 #include "rt_trace.h"
 #include "rt_kernels.h"
+#include "rt_packet_asm.h"
+
+#ifdef RT_WAVES
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES)))
+#else
+#define RT_WAVES_ATTR
+#endif
 
 #include <algorithm>
 
@@ -134,44 +141,81 @@ __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3
 }
 
 // ---------------------------------------------------------------- LBVH traversal
-// Node i = 4 float4: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (ref0, ref1, -, -).
-// ref >= 0: inner node; ref < 0: leaf holding sorted primitive ~ref.  Boxes are
-// padded at build time and the slab test is widened, so a primitive the exact
-// test would accept is never culled; the exact tests and the
-// (distance, primitive id) lexicographic minimum then give the brute-force answer.
-__device__ inline float slab_near(float lo, float hi, float o, float inv, float& tfar) {
-    float t0 = (lo - o) * inv, t1 = (hi - o) * inv;
-    tfar = fmaxf(t0, t1);
-    return fminf(t0, t1);
-}
-__device__ inline bool box_hit(F3 lo, F3 hi, F3 o, F3 inv, float tmax, float& tnear) {
-    float fx, fy, fz;
-    float nx = slab_near(lo.x, hi.x, o.x, inv.x, fx);
-    float ny = slab_near(lo.y, hi.y, o.y, inv.y, fy);
-    float nz = slab_near(lo.z, hi.z, o.z, inv.z, fz);
-    // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a slab of
-    // a zero direction component), which keeps the test conservative.
-    float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
-    float tf = fminf(fminf(fx, fy), fz);
-    tnear = tn;
-    return tn <= tf * 1.0000005f && tn <= tmax;
-}
-
+// Node i = 16 floats: child 0 box as (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z), child 1 box
+// the same way, then (ref0, ref1, -, -).  ref >= 0: inner node; ref < 0: leaf holding
+// sorted primitive ~ref.  Boxes are padded at build time and the slab test is
+// widened, so a primitive the exact test would accept is never culled; the exact
+// tests and the (distance, primitive id) lexicographic minimum then give the
+// brute-force answer whatever the visiting order.
 #define LBVH_STACK 96   // >= deepest possible tree: 63 Morton bits + 32 index tie-break bits
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4f* cv4p;
 
+// Per-ray constants of the slab test t = plane * inv - o * inv (one fused multiply-add
+// per plane, two planes per packed instruction).  A zero direction component would
+// make inv infinite and the difference an inf - inf; a 1e-20 slope keeps the
+// arithmetic finite and means the same thing for any box of a scene (the ray stays
+// inside or outside that slab).  The box test only has to be conservative -- boxes
+// are padded by 1e-4 of their coordinates, far above this rounding -- it never
+// decides a hit.
+struct SlabRay {
+    F3 inv, noi;   // 1 / d and -(o / d)
+};
+__device__ inline SlabRay slab_ray(F3 o, F3 d) {
+    F3 ds = f3(__builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x,
+               __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y,
+               __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z);
+    SlabRay r;
+    r.inv = f3(1.0f / ds.x, 1.0f / ds.y, 1.0f / ds.z);
+    r.noi = f3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+    return r;
+}
+
+// One box from its three (t at lo plane, t at hi plane) pairs.  OCT < 8: the signs of
+// the direction are known (bit k set = negative along axis k), so near and far planes
+// are picked at compile time; OCT == 8: any direction, min / max per axis.
+template <int OCT>
+__device__ inline bool slab_hit(v2f x, v2f y, v2f z, float tmax, float& tnear) {
+    float nx, fx, ny, fy, nz, fz;
+    if (OCT == 8) {
+        nx = fminf(x.x, x.y); fx = fmaxf(x.x, x.y);
+        ny = fminf(y.x, y.y); fy = fmaxf(y.x, y.y);
+        nz = fminf(z.x, z.y); fz = fmaxf(z.x, z.y);
+    } else {
+        nx = (OCT & 1) ? x.y : x.x; fx = (OCT & 1) ? x.x : x.y;
+        ny = (OCT & 2) ? y.y : y.x; fy = (OCT & 2) ? y.x : y.y;
+        nz = (OCT & 4) ? z.y : z.x; fz = (OCT & 4) ? z.x : z.y;
+    }
+    float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);
+    float tf = fminf(fminf(fx, fy), fz);
+    tnear = tn;
+    return tn <= fminf(tf * 1.0000005f, tmax);
+}
+template <int OCT>
+__device__ inline void box_pair(v4f q0, v4f q1, v4f q2, const SlabRay& R, float tmax, bool& h0, bool& h1,
+                                float& tn0, float& tn1) {
+    const v2f ix = {R.inv.x, R.inv.x}, iy = {R.inv.y, R.inv.y}, iz = {R.inv.z, R.inv.z};
+    const v2f ox = {R.noi.x, R.noi.x}, oy = {R.noi.y, R.noi.y}, oz = {R.noi.z, R.noi.z};
+    v2f x0 = __builtin_elementwise_fma((v2f){q0.x, q0.y}, ix, ox);
+    v2f y0 = __builtin_elementwise_fma((v2f){q0.z, q0.w}, iy, oy);
+    v2f z0 = __builtin_elementwise_fma((v2f){q1.x, q1.y}, iz, oz);
+    v2f x1 = __builtin_elementwise_fma((v2f){q1.z, q1.w}, ix, ox);
+    v2f y1 = __builtin_elementwise_fma((v2f){q2.x, q2.y}, iy, oy);
+    v2f z1 = __builtin_elementwise_fma((v2f){q2.z, q2.w}, iz, oz);
+    h0 = slab_hit<OCT>(x0, y0, z0, tmax, tn0);
+    h1 = slab_hit<OCT>(x1, y1, z1, tmax, tn1);
+}
+
 // exact test of one tree-ordered leaf record (see rt_lbvh.hip: k_leaves)
 __device__ inline bool leaf_test(F3 o, F3 d, double dd, float4 l0, float4 l1, float4 l2, float dmax,
-                                 float& d2, TraceStats& ts) {
+                                 float& d2) {
     if (fbits(l2.z) != 0u) {
         float tf;
-        ts.lane_prims++;
         return sphere_test(o, d, dd, l0, dmax, d2, tf);
     }
     TriHit h;
-    ts.lane_prims++;
     bool hit = tri_test(o, d, f3(l0.x, l0.y, l0.z), f3(l0.w, l1.x, l1.y), f3(l1.z, l1.w, l2.x), dmax, h);
     d2 = h.d2;
     return hit;
@@ -186,20 +230,21 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
     if (!active) return;
     double dd = (double)dot3(d, d);
     float ddf = dot3(d, d);
-    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const SlabRay R = slab_ray(o, d);
     // ray-parameter bound equivalent to the squared-distance bound, widened
     float tmax = (dmax < __builtin_inff()) ? __builtin_sqrtf(dmax / ddf) * 1.00001f : __builtin_inff();
     int stack[LBVH_STACK];
     int sp = 0;
     int cur = S.root;
+    const v4f* nodes = (const v4f*)S.nodes;
     while (true) {
         if (cur >= 0) {
-            const float4* nd = S.nodes + 4 * (size_t)cur;
-            float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            const v4f* nd = nodes + 4 * (size_t)cur;
+            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
             ts.nodes++; ts.lane_nodes++;
             float tn0, tn1;
-            bool h0 = box_hit(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), o, inv, tmax, tn0);
-            bool h1 = box_hit(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), o, inv, tmax, tn1);
+            bool h0, h1;
+            box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
             int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
@@ -214,8 +259,9 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
             float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
             int prim = (int)fbits(l2.y);
             if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
+            ts.lane_prims++;
             float d2 = 0;
-            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, ts)) {
+            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2)) {
                 if (ANY) { best = prim; best_d2 = d2; return; }
                 if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
                     best = prim;
@@ -232,116 +278,166 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
 // Packet traversal: the 64 rays of a wave walk the tree TOGETHER.  The current
 // node is wave-uniform, so node and leaf records come through the scalar data
 // path (one fetch per wave, operands in SGPRs), the traversal stack lives in the
-// lanes of two VGPRs (entry k in lane k, popped with v_readlane), and there is
+// lanes of two VGPRs (entry k in lane k: v_writelane / v_readlane), and there is
 // no divergence inside the loop.  A child is entered when ANY lane's ray hits its
 // box; the nearer child by majority vote goes first.  Every lane still applies its
 // own distance bound and the exact tests, so the result per ray is the same as
 // the per-lane walk (and as brute force); only the visiting order is shared.
-// All 64 lanes must call.
+// When all rays of the wave point into the same octant -- primary rays, shadow
+// rays of a directional light -- the descent runs a variant compiled for that
+// octant, which needs no per-axis min / max.  All 64 lanes must call.
 __device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// slab test against a box held in SGPRs; oi = o * inv precomputed per ray.  One
-// fused multiply-add per plane: the box test only has to be conservative (boxes
-// are padded by 1e-4 of their coordinates at build time, far above the rounding
-// of lo*inv - o*inv), it never decides a hit.
-__device__ inline bool box_hit_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, F3 inv,
-                                   F3 oi, float tmax, float& tnear) {
-    float ax = __builtin_fmaf(lox, inv.x, -oi.x), bx = __builtin_fmaf(hix, inv.x, -oi.x);
-    float ay = __builtin_fmaf(loy, inv.y, -oi.y), by = __builtin_fmaf(hiy, inv.y, -oi.y);
-    float az = __builtin_fmaf(loz, inv.z, -oi.z), bz = __builtin_fmaf(hiz, inv.z, -oi.z);
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    tnear = tn;
-    return tn <= tf * 1.0000005f && tn <= tmax;
+// one entry of the wave-shared stack: lane `sel` of v takes the wave-uniform value
+__device__ inline void lane_write(int& v, int value, int sel) {
+    // the lane select goes through m0 (saved and restored): gfx9 VALU encodings may name
+    // only one SGPR besides it
+    int keep;
+    value = __builtin_amdgcn_readfirstlane(value);
+    sel = __builtin_amdgcn_readfirstlane(sel);
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(v), "=&s"(keep) : "s"(value), "s"(sel));
 }
 
-template <bool ANY>
-__device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
-                                         float& best_d2, TraceStats& ts) {
+#define PACKET_DONE ((int)0x80000000)   // ~(2^31 - 1): never a leaf slot
+
+struct PacketState {
+    int sp;                        // wave-uniform stack depth
+    int vs0, vs1;                  // entries 0..63 / 64..127, one per lane
+    unsigned long long alive;      // lanes still looking for a hit
+    uint32_t n_nodes, n_lane_nodes;
+};
+
+// Walks inner nodes from `cur` until a leaf comes up (returned, < 0) or the stack is
+// empty (PACKET_DONE).
+template <int OCT>
+__device__ inline int packet_descend(cv4p nodes, int cur, const SlabRay& R, float tmax, PacketState& st) {
+    while (cur >= 0) {
+        cv4p nd = nodes + 4 * (size_t)cur;
+        v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        float tn0, tn1;
+        bool h0, h1;
+        box_pair<OCT>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
+        const unsigned long long m0 = ballot64(h0) & st.alive, m1 = ballot64(h1) & st.alive;
+        st.n_nodes++;
+        st.n_lane_nodes += (uint32_t)__popcll(st.alive);
+        const int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+        if (m0 != 0ull && m1 != 0ull) {
+            // lanes that hit both boxes vote with their nearer one, the others with the one they hit
+            const unsigned long long le = ballot64(tn0 <= tn1);
+            const int v0 = __popcll(m0 & (~m1 | le));
+            const int v1 = __popcll(m0 | m1) - v0;
+            const bool swap = v1 > v0;
+            const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+            if (st.sp < 64) lane_write(st.vs0, farc, st.sp);
+            else lane_write(st.vs1, farc, st.sp - 64);
+            st.sp++;
+            cur = nearc;
+        } else if (m0 != 0ull) cur = c0;
+        else if (m1 != 0ull) cur = c1;
+        else {
+            if (st.sp == 0) return PACKET_DONE;
+            st.sp--;
+            cur = (st.sp < 64) ? __builtin_amdgcn_readlane(st.vs0, st.sp) : __builtin_amdgcn_readlane(st.vs1, st.sp - 64);
+        }
+    }
+    return cur;
+}
+
+template <bool ANY, bool FAST>
+__device__ inline void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
+                                              float& best_d2, TraceStats& ts) {
     best = -1;
     best_d2 = dmax;
-    bool alive = active;
-    if (ballot64(alive) == 0ull) return;
+    PacketState st;
+    st.alive = ballot64(active);
+    if (st.alive == 0ull) return;
     const int lane = (int)(threadIdx.x & 63);
     double dd = (double)dot3(d, d);
     float ddf = dot3(d, d);
-    // A zero direction component would make inv infinite and lo*inv - o*inv an
-    // inf - inf; a 1e-20 slope keeps the slab arithmetic finite and means the same
-    // thing for any box of this scene (the ray stays inside or outside that slab).
-    F3 ds = f3(__builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x,
-               __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y,
-               __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z);
-    F3 inv = f3(1.0f / ds.x, 1.0f / ds.y, 1.0f / ds.z);
-    F3 oi = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    const SlabRay R = slab_ray(o, d);
     float tmax = (dmax < __builtin_inff()) ? __builtin_sqrtf(dmax / ddf) * 1.00001f : __builtin_inff();
+    // octant shared by every live ray of the wave, or 8
+    int oct = 0;
+    {
+        const unsigned long long sx = ballot64(R.inv.x < 0.0f) & st.alive, sy = ballot64(R.inv.y < 0.0f) & st.alive,
+                                 sz = ballot64(R.inv.z < 0.0f) & st.alive;
+        const bool uniform = (sx == 0ull || sx == st.alive) && (sy == 0ull || sy == st.alive) && (sz == 0ull || sz == st.alive);
+        oct = uniform ? ((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0)) : 8;
+    }
     // The tree is read-only for the whole launch and the record address is
     // wave-uniform: reading through the constant address space makes the compiler
     // fetch a record with scalar loads (s_load_dwordx16) instead of 64 identical
     // per-lane loads.
     cv4p nodes = (cv4p)S.nodes;
     cv4p leaf = (cv4p)S.leaf;
-    int vs0 = 0, vs1 = 0;   // 128-entry wave-shared stack, one entry per lane
-    int sp = 0;
+    st.sp = 0; st.vs0 = 0; st.vs1 = 0; st.n_nodes = 0; st.n_lane_nodes = 0;
+    uint32_t n_sph = 0, n_tri = 0, n_lane_prims = 0;
     int cur = S.root;
-    // statistics are kept wave-uniform (scalar registers) and added once at the end
-    uint32_t n_nodes = 0, n_sph = 0, n_tri = 0, n_lane_nodes = 0, n_lane_prims = 0;
     unsigned long long t0 = S.profile ? __builtin_readcyclecounter() : 0ull;
+    const pka_v2f pa = {R.inv.x, R.inv.y}, pb = {R.inv.z, R.noi.x}, pc = {R.noi.y, R.noi.z};
     while (true) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        if (cur >= 0) {
-            cv4p nd = nodes + 4 * (size_t)cur;
-            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            float tn0, tn1;
-            bool h0 = box_hit_fma(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oi, tmax, tn0) && alive;
-            bool h1 = box_hit_fma(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oi, tmax, tn1) && alive;
-            unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
-            n_nodes++;
-            n_lane_nodes += (uint32_t)__popcll(ballot64(alive));
-            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
-            if (m0 != 0ull && m1 != 0ull) {
-                int v0 = __popcll(ballot64(h0 && (!h1 || tn0 <= tn1)));
-                int v1 = __popcll(m1) + __popcll(m0) - __popcll(m0 & m1) - v0;   // the lanes that prefer child 1
-                bool swap = v1 > v0;
-                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                // push: entry sp lives in lane sp & 63 of vs0 / vs1
-                if (sp < 64) vs0 = (lane == sp) ? farc : vs0;
-                else if (sp < 128) vs1 = (lane == sp - 64) ? farc : vs1;
-                sp = (sp < 128) ? sp + 1 : sp;
-                cur = nearc;
-                continue;
-            } else if (m0 != 0ull) { cur = c0; continue; }
-            else if (m1 != 0ull) { cur = c1; continue; }
+        if (FAST) {
+            int steps = 0;
+            switch (oct) {
+                case 0: pka_descend_0(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                case 1: pka_descend_1(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                case 2: pka_descend_2(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                case 3: pka_descend_3(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                case 4: pka_descend_4(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                case 5: pka_descend_5(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                case 6: pka_descend_6(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                case 7: pka_descend_7(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+                default: pka_descend_any(S.nodes, st.alive, pa, pb, pc, tmax, cur, st.sp, steps, st.vs0); break;
+            }
+            st.n_nodes += (uint32_t)steps;
+            st.n_lane_nodes += (uint32_t)steps * (uint32_t)__popcll(st.alive);
         } else {
-            cv4p lf = leaf + 3 * (size_t)(~cur);
-            v4f r0 = lf[0], r1 = lf[1], r2 = lf[2];
-            float4 l0 = make_float4(r0.x, r0.y, r0.z, r0.w), l1 = make_float4(r1.x, r1.y, r1.z, r1.w),
-                   l2 = make_float4(r2.x, r2.y, r2.z, r2.w);
-            int prim = (int)fbits(l2.y);
-            if (fbits(l2.z) != 0u) n_sph++; else n_tri++;
-            n_lane_prims += (uint32_t)__popcll(ballot64(alive));
-            if (alive) {
-                float d2 = 0;
-                TraceStats dummy;
-                if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, dummy)) {
-                    if (ANY) { best = prim; best_d2 = d2; alive = false; }
-                    else if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
-                        best = prim;
-                        best_d2 = d2;
-                        tmax = __builtin_sqrtf(d2 / ddf) * 1.00001f;
-                    }
+            cur = packet_descend<8>(nodes, cur, R, tmax, st);
+        }
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        if (cur == PACKET_DONE) break;
+        cv4p lf = leaf + 3 * (size_t)(~cur);
+        v4f r0 = lf[0], r1 = lf[1], r2 = lf[2];
+        float4 l0 = make_float4(r0.x, r0.y, r0.z, r0.w), l1 = make_float4(r1.x, r1.y, r1.z, r1.w),
+               l2 = make_float4(r2.x, r2.y, r2.z, r2.w);
+        int prim = (int)fbits(l2.y);
+        if (fbits(l2.z) != 0u) n_sph++; else n_tri++;
+        n_lane_prims += (uint32_t)__popcll(st.alive);
+        bool found = false;
+        if ((st.alive >> lane) & 1ull) {
+            float d2 = 0;
+            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2)) {
+                if (ANY) { best = prim; best_d2 = d2; found = true; }
+                else if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
+                    best = prim;
+                    best_d2 = d2;
+                    tmax = __builtin_sqrtf(d2 / ddf) * 1.00001f;
                 }
             }
-            if (ANY && ballot64(alive) == 0ull) break;
         }
-        if (sp == 0) break;
-        sp--;
-        cur = (sp < 64) ? __builtin_amdgcn_readlane(vs0, sp) : __builtin_amdgcn_readlane(vs1, sp - 64);
+        if (ANY) {
+            st.alive &= ~ballot64(found);
+            if (st.alive == 0ull) break;
+        }
+        if (st.sp == 0) break;
+        st.sp--;
+        cur = (st.sp < 64) ? __builtin_amdgcn_readlane(st.vs0, st.sp) : __builtin_amdgcn_readlane(st.vs1, st.sp - 64);
     }
     if (lane == 0) {
-        ts.nodes += n_nodes; ts.sph += n_sph; ts.tri += n_tri;
-        ts.lane_nodes += n_lane_nodes; ts.lane_prims += n_lane_prims;
-        if (S.profile) { ts.walk_cycles += __builtin_readcyclecounter() - t0; ts.steps += n_nodes + n_sph + n_tri; ts.walks++; }
+        ts.nodes += st.n_nodes; ts.sph += n_sph; ts.tri += n_tri;
+        ts.lane_nodes += st.n_lane_nodes; ts.lane_prims += n_lane_prims;
+        if (S.profile) { ts.walk_cycles += __builtin_readcyclecounter() - t0; ts.steps += st.n_nodes + n_sph + n_tri; ts.walks++; }
     }
+}
+
+// Trees at most 64 deep (all but degenerate scenes) take the hand-scheduled descent, whose
+// stack is one register wide; deeper ones the compiled one.
+template <bool ANY>
+__device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
+                                         float& best_d2, TraceStats& ts) {
+    if (S.depth <= 64) lbvh_trace_packet_impl<ANY, true>(S, active, o, d, dmax, best, best_d2, ts);
+    else lbvh_trace_packet_impl<ANY, false>(S, active, o, d, dmax, best, best_d2, ts);
 }
 
 template <int ACCEL, bool ANY>
@@ -529,7 +625,7 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc&
 }
 
 template <int ACCEL>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
+__global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
     if (C->overflow) return;   // ray slots past an overflow were never written: the host re-runs the batch
     const uint32_t start = gen_start(C, g);
@@ -651,7 +747,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int
 // The shadow query of getColor (src/raytrace.cpp:523-539) for every
 // (hit, light) pair of the generation: one work item per pair.
 template <int ACCEL>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene S, DPool P, DCounters* C, int g) {
+__global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPool P, DCounters* C, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
     if (C->overflow) return;
     const uint32_t nh = C->hit_count[g];

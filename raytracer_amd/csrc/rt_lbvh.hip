@@ -10,7 +10,7 @@
 // The tree only has to be CONSERVATIVE: traversal re-runs the reference's exact
 // primitive tests, so the image equals brute force however the tree is shaped.
 //
-// Node i = 4 float4: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (ref0, ref1, -, -)
+// Node i = 4 float4: child 0 box (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z), child 1 box likewise, (ref0, ref1, -, -)
 // ref >= 0: inner node, ref < 0: leaf = sorted primitive slot ~ref.
 #include "rt_device.h"
 #include "rt_kernels.h"
@@ -143,9 +143,9 @@ __global__ void k_hierarchy(const unsigned long long* keys, int n, int* child /*
 
 __device__ inline void store_child_box(float4* nodes, int node, int side, const Box& b) {
     float* f = (float*)(nodes + 4 * (size_t)node);
-    float* dst = f + 6 * side;   // floats 0..5 = box 0, 6..11 = box 1
-    dst[0] = b.lo[0]; dst[1] = b.lo[1]; dst[2] = b.lo[2];
-    dst[3] = b.hi[0]; dst[4] = b.hi[1]; dst[5] = b.hi[2];
+    float* dst = f + 6 * side;   // floats 0..5 = box 0, 6..11 = box 1, each (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
+    dst[0] = b.lo[0]; dst[1] = b.hi[0]; dst[2] = b.lo[1];
+    dst[3] = b.hi[1]; dst[4] = b.lo[2]; dst[5] = b.hi[2];
 }
 
 __global__ void k_refit(const Box* boxes, const uint32_t* sorted, int n, const int* child, const int* parent_inner,
@@ -165,8 +165,8 @@ __global__ void k_refit(const Box* boxes, const uint32_t* sorted, int n, const i
         const float* f = (const float*)(nodes + 4 * (size_t)node);
         const float* sib = f + 6 * (1 - side);
         for (int k = 0; k < 3; k++) {
-            float slo = __hip_atomic_load(&sib[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float shi = __hip_atomic_load(&sib[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float slo = __hip_atomic_load(&sib[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float shi = __hip_atomic_load(&sib[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             b.lo[k] = fminf(b.lo[k], slo);
             b.hi[k] = fmaxf(b.hi[k], shi);
         }
@@ -197,10 +197,21 @@ __global__ void k_leaves(const float4* sph, int ns, const float4* tri, const uin
     leaf[3 * (size_t)j] = q0; leaf[3 * (size_t)j + 1] = q1; leaf[3 * (size_t)j + 2] = q2;
 }
 
+// Depth of the tree = the largest number of inner nodes above a leaf: bounds the
+// traversal stacks.
+__global__ void k_depth(const int* parent_inner, const int* parent_leaf, int n, uint32_t* out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int dpt = 0;
+    if (j < n)
+        for (int link = parent_leaf[j]; link >= 0; link = parent_inner[link >> 1]) dpt++;
+    for (int off = 32; off > 0; off >>= 1) dpt = max(dpt, __shfl_down(dpt, off));
+    if ((threadIdx.x & 63) == 0 && dpt > 0) atomicMax(out, (uint32_t)dpt);
+}
+
 #define L_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(vals2); (void)hipFree(leaf); return (int)e_; } } while (0)
 
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
-              int** prim_idx_out, float4** leaf_out, int* root) {
+              int** prim_idx_out, float4** leaf_out, int* root, int* depth) {
     int n = ns + nt;
     *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *root = 0;
     if (n < 2) return (int)hipErrorInvalidValue;
@@ -213,7 +224,7 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
         for (void* p : ptrs) (void)hipFree(p);
     };
     L_TRY(hipMalloc(&boxes, (size_t)n * sizeof(Box)));
-    L_TRY(hipMalloc(&scene, 6 * sizeof(uint32_t)));
+    L_TRY(hipMalloc(&scene, 8 * sizeof(uint32_t)));
     L_TRY(hipMalloc(&keys, (size_t)n * 8)); L_TRY(hipMalloc(&keys2, (size_t)n * 8));
     L_TRY(hipMalloc(&vals, (size_t)n * 4)); L_TRY(hipMalloc(&vals2, (size_t)n * 4));
     L_TRY(hipMalloc(&child, (size_t)(n - 1) * 2 * sizeof(int)));
@@ -222,7 +233,7 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     L_TRY(hipMalloc(&flags, (size_t)(n - 1) * sizeof(uint32_t)));
     L_TRY(hipMalloc(&nodes, (size_t)(n - 1) * 4 * sizeof(float4)));
     L_TRY(hipMalloc(&leaf, (size_t)n * 3 * sizeof(float4)));
-    uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};   // [6] = tree depth
     L_TRY(hipMemcpyAsync(scene, init, sizeof(init), hipMemcpyHostToDevice, st));
     L_TRY(hipMemsetAsync(flags, 0, (size_t)(n - 1) * sizeof(uint32_t), st));
     int blocks = (n + 255) / 256;
@@ -235,8 +246,12 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, st, keys2, n, child, pin, plf);
     hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, boxes, vals2, n, child, pin, plf, flags, nodes);
     hipLaunchKernelGGL(k_leaves, dim3(blocks), dim3(256), 0, st, sph, ns, tri, vals2, n, leaf);
+    hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, st, pin, plf, n, scene + 6);
     L_TRY(hipGetLastError());
+    uint32_t dpt = 0;
+    L_TRY(hipMemcpyAsync(&dpt, scene + 6, sizeof(dpt), hipMemcpyDeviceToHost, st));
     L_TRY(hipStreamSynchronize(st));
+    *depth = (int)dpt;
     cleanup();
     *nodes_out = nodes;
     *prim_idx_out = (int*)vals2;   // sorted primitive ids, kept by the caller

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Static instruction mix per kernel of the HIP sources, from the compiler's assembly.
+
+  python tools/isa_stats.py [extra hipcc flags...]
+
+Compiles raytracer_amd/csrc/rt_kernels.hip for gfx950 to assembly (device only) and
+prints, per kernel: VGPRs, SGPRs, scratch bytes, occupancy, and static counts of vector ALU,
+vector moves, scalar ALU, branches, scalar loads, global loads / stores."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "raytracer_amd", "csrc")
+
+
+def main():
+    out = os.path.join(tempfile.gettempdir(), "rt_kernels.s")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
+           os.path.join(SRC, "rt_kernels.hip")] + sys.argv[1:]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    name, rows, cur = None, [], None
+    for line in open(out):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name = m.group(1)
+            cur = dict(valu=0, vmov=0, salu=0, branch=0, smem=0, gload=0, gstore=0, scratch_ops=0)
+            continue
+        if cur is None:
+            continue
+        t = line.strip()
+        if t.startswith("v_mov") or t.startswith("v_pk_mov"):
+            cur["vmov"] += 1; cur["valu"] += 1
+        elif t.startswith("v_"):
+            cur["valu"] += 1
+        elif t.startswith("s_cbranch") or t.startswith("s_branch"):
+            cur["branch"] += 1
+        elif t.startswith("s_load") or t.startswith("s_buffer_load"):
+            cur["smem"] += 1
+        elif t.startswith("s_") and not t.startswith(("s_waitcnt", "s_nop", "s_endpgm")):
+            cur["salu"] += 1
+        elif t.startswith("global_load") or t.startswith("flat_load"):
+            cur["gload"] += 1
+        elif t.startswith("global_store") or t.startswith("flat_store") or t.startswith("global_atomic"):
+            cur["gstore"] += 1
+        elif t.startswith("scratch_"):
+            cur["scratch_ops"] += 1
+        for key, pat in (("vgpr", r"; NumVgprs: (\d+)"), ("sgpr", r"; TotalNumSgprs: (\d+)"),
+                         ("scratch", r"; ScratchSize: (\d+)"), ("occ", r"; Occupancy: (\d+)")):
+            m = re.match(pat, t)
+            if m:
+                cur[key] = int(m.group(1))
+                if key == "occ":
+                    rows.append((name, cur)); cur = None
+                break
+    print(f"{'kernel':44s} vgpr sgpr scr occ | valu vmov salu  br smem gld gst scr_ops")
+    for n, c in rows:
+        short = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+        print(f"{short:44s} {c.get('vgpr', 0):4d} {c.get('sgpr', 0):4d} {c.get('scratch', 0):3d} {c.get('occ', 0):3d} | "
+              f"{c['valu']:4d} {c['vmov']:4d} {c['salu']:4d} {c['branch']:3d} {c['smem']:4d} {c['gload']:3d} {c['gstore']:3d} {c['scratch_ops']:4d}")
+
+
+if __name__ == "__main__":
+    main()
