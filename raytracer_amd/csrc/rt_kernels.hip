@@ -99,7 +99,7 @@ struct TraceStats {
 
 template <bool ANY>
 __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
-                                   int& best, float& best_d2, TraceStats& ts) {
+                                   int& best, float& best_d2, HitUV& uv, TraceStats& ts) {
     double dd = (double)dot3(d, d);
     best = -1;
     best_d2 = dmax;
@@ -113,7 +113,7 @@ __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3
             for (int i = 0; i < n; i++) {
                 float d2, tf;
                 if (sphere_test(o, d, dd, lds[i], dmax, d2, tf)) {
-                    if (best < 0 || d2 < best_d2) { best = base + i; best_d2 = d2; }
+                    if (best < 0 || d2 < best_d2) { best = base + i; best_d2 = d2; uv.a = tf; }
                     if (ANY) { done = true; break; }
                 }
             }
@@ -131,7 +131,7 @@ __device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3
                 tri_load(lds + 3 * i, a, ab, ac);
                 TriHit h;
                 if (tri_test(o, d, a, ab, ac, dmax, h)) {
-                    if (best < 0 || h.d2 < best_d2) { best = S.ns + base + i; best_d2 = h.d2; }
+                    if (best < 0 || h.d2 < best_d2) { best = S.ns + base + i; best_d2 = h.d2; uv.a = (float)h.beta; uv.b = (float)h.gamma; }
                     if (ANY) { done = true; break; }
                 }
             }
@@ -162,15 +162,25 @@ typedef const __attribute__((address_space(4))) v4f* cv4p;
 // decides a hit.
 struct SlabRay {
     F3 inv, noi;   // 1 / d and -(o / d)
+    float inv_dd;  // 1 / dot(d, d)
 };
 __device__ inline SlabRay slab_ray(F3 o, F3 d) {
     F3 ds = f3(__builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x,
                __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y,
                __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z);
     SlabRay r;
-    r.inv = f3(1.0f / ds.x, 1.0f / ds.y, 1.0f / ds.z);
+    // hardware reciprocals (1 ulp): the slab test is conservative by far more than that
+    r.inv = f3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
     r.noi = f3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+    r.inv_dd = __builtin_amdgcn_rcpf(dot3(d, d));
     return r;
+}
+// Ray-parameter bound equivalent to a squared-distance bound (d2 = t^2 dot(d, d)), widened
+// by 1e-4 -- three orders of magnitude above the error of the approximate reciprocal and
+// square root -- so it only ever culls boxes that lie wholly beyond the bound.  An
+// infinite (or NaN) bound culls nothing.
+__device__ inline float slab_tmax(const SlabRay& r, float d2) {
+    return __builtin_amdgcn_sqrtf(d2 * r.inv_dd) * 1.0001f;
 }
 
 // One box from its three (t at lo plane, t at hi plane) pairs.  OCT < 8: the signs of
@@ -210,29 +220,25 @@ __device__ inline void box_pair(v4f q0, v4f q1, v4f q2, const SlabRay& R, float 
 
 // exact test of one tree-ordered leaf record (see rt_lbvh.hip: k_leaves)
 __device__ inline bool leaf_test(F3 o, F3 d, double dd, float4 l0, float4 l1, float4 l2, float dmax,
-                                 float& d2) {
-    if (fbits(l2.z) != 0u) {
-        float tf;
-        return sphere_test(o, d, dd, l0, dmax, d2, tf);
-    }
+                                 float& d2, HitUV& uv) {
+    if (fbits(l2.z) != 0u) return sphere_test(o, d, dd, l0, dmax, d2, uv.a);
     TriHit h;
     bool hit = tri_test(o, d, f3(l0.x, l0.y, l0.z), f3(l0.w, l1.x, l1.y), f3(l1.z, l1.w, l2.x), dmax, h);
     d2 = h.d2;
+    uv.a = (float)h.beta; uv.b = (float)h.gamma;
     return hit;
 }
 
 // Per-lane while-while traversal with a private stack: every lane walks its own path.
 template <bool ANY>
 __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
-                                  float& best_d2, TraceStats& ts) {
+                                  float& best_d2, HitUV& uv, TraceStats& ts) {
     best = -1;
     best_d2 = dmax;
     if (!active) return;
     double dd = (double)dot3(d, d);
-    float ddf = dot3(d, d);
     const SlabRay R = slab_ray(o, d);
-    // ray-parameter bound equivalent to the squared-distance bound, widened
-    float tmax = (dmax < __builtin_inff()) ? __builtin_sqrtf(dmax / ddf) * 1.00001f : __builtin_inff();
+    float tmax = slab_tmax(R, dmax);
     int stack[LBVH_STACK];
     int sp = 0;
     int cur = S.root;
@@ -261,12 +267,14 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
             if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
             ts.lane_prims++;
             float d2 = 0;
-            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2)) {
+            HitUV cand;
+            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand)) {
                 if (ANY) { best = prim; best_d2 = d2; return; }
                 if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
                     best = prim;
                     best_d2 = d2;
-                    tmax = __builtin_sqrtf(d2 / ddf) * 1.00001f;
+                    uv = cand;
+                    tmax = slab_tmax(R, d2);
                 }
             }
         }
@@ -346,7 +354,7 @@ __device__ inline int packet_descend(cv4p nodes, int cur, const SlabRay& R, floa
 
 template <bool ANY, bool FAST>
 __device__ inline void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
-                                              float& best_d2, TraceStats& ts) {
+                                              float& best_d2, HitUV& uv, TraceStats& ts) {
     best = -1;
     best_d2 = dmax;
     PacketState st;
@@ -354,9 +362,8 @@ __device__ inline void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o
     if (st.alive == 0ull) return;
     const int lane = (int)(threadIdx.x & 63);
     double dd = (double)dot3(d, d);
-    float ddf = dot3(d, d);
     const SlabRay R = slab_ray(o, d);
-    float tmax = (dmax < __builtin_inff()) ? __builtin_sqrtf(dmax / ddf) * 1.00001f : __builtin_inff();
+    float tmax = slab_tmax(R, dmax);
     // octant shared by every live ray of the wave, or 8
     int oct = 0;
     {
@@ -407,12 +414,14 @@ __device__ inline void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o
         bool found = false;
         if ((st.alive >> lane) & 1ull) {
             float d2 = 0;
-            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2)) {
+            HitUV cand;
+            if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand)) {
                 if (ANY) { best = prim; best_d2 = d2; found = true; }
                 else if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
                     best = prim;
                     best_d2 = d2;
-                    tmax = __builtin_sqrtf(d2 / ddf) * 1.00001f;
+                    uv = cand;
+                    tmax = slab_tmax(R, d2);
                 }
             }
         }
@@ -435,17 +444,18 @@ __device__ inline void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o
 // stack is one register wide; deeper ones the compiled one.
 template <bool ANY>
 __device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
-                                         float& best_d2, TraceStats& ts) {
-    if (S.depth <= 64) lbvh_trace_packet_impl<ANY, true>(S, active, o, d, dmax, best, best_d2, ts);
-    else lbvh_trace_packet_impl<ANY, false>(S, active, o, d, dmax, best, best_d2, ts);
+                                         float& best_d2, HitUV& uv, TraceStats& ts) {
+    if (S.depth <= 64) lbvh_trace_packet_impl<ANY, true>(S, active, o, d, dmax, best, best_d2, uv, ts);
+    else lbvh_trace_packet_impl<ANY, false>(S, active, o, d, dmax, best, best_d2, uv, ts);
 }
 
 template <int ACCEL, bool ANY>
 __device__ inline void trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
-                             int& best, float& best_d2, TraceStats& ts) {
-    if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, ts);
-    else if (ACCEL == 2) lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, ts);
-    else lbvh_trace_packet<ANY>(S, active, o, d, dmax, best, best_d2, ts);
+                             int& best, float& best_d2, HitUV& uv, TraceStats& ts) {
+    uv.a = 0; uv.b = 0;
+    if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, uv, ts);
+    else if (ACCEL == 2) lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, uv, ts);
+    else lbvh_trace_packet<ANY>(S, active, o, d, dmax, best, best_d2, uv, ts);
 }
 
 __device__ inline void flush_stats(DCounters* C, int which, const TraceStats& ts) {
@@ -599,13 +609,13 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc&
     RayRec R = load_ray(P, G, g, inrange ? i : 0, r);
     bool active = inrange && R.valid;
     F3 o = R.o, d = R.d;
-    int best; float best_d2;
-    trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, ts);
+    int best; float best_d2; HitUV uv;
+    trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, uv, ts);
     bool hit = active && best >= 0;
     bool refl = false, refr = false;
     if (hit) {
         F3 point, normal; int mat;
-        make_hit(S, o, d, (double)dot3(d, d), best, __builtin_inff(), point, normal, mat);
+        make_hit_uv(S, o, d, best, uv, point, normal, mat);
         P.hp[i] = make_float4(point.x, point.y, point.z, bitsf((uint32_t)best));
         P.hn[i] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat));
         if (g + 1 <= S.max_depth) {   // deeper children are never traced (src/raytrace.cpp:132-135)
@@ -760,8 +770,8 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
         F3 point = f3(P.hp[P.hitlist[h]]);
         F3 I; float dist2;
         light_dir(S.lights[j], point, I, dist2);
-        int best; float best_d2;
-        trace<ACCEL, true>(S, lds, active, point, I, dist2, best, best_d2, ts);
+        int best; float best_d2; HitUV uv;
+        trace<ACCEL, true>(S, lds, active, point, I, dist2, best, best_d2, uv, ts);
         if (active) P.occl[k] = (best >= 0) ? 1 : 0;
     };
     if (ACCEL == 1) {
@@ -913,19 +923,44 @@ __device__ inline uint8_t quantise(float c) {
     return (uint8_t)((i < 0) ? 0 : (i > 255) ? 255 : i);
 }
 
+// One pixel per thread, but a pixel's samples lie 16 * spp bytes apart from its
+// neighbour's: read per thread, every load touches 64 cache lines.  The block therefore
+// stages its 256 pixels through LDS, 16 samples at a time: coalesced loads (lane l takes
+// record l of the block's contiguous run), then each thread adds up its own pixel in
+// sample order.  49 floats per pixel row keeps the per-thread reads off each other's banks.
+#define FIN_CHUNK 16
+#define FIN_ROW (3 * FIN_CHUNK + 1)
 __global__ __launch_bounds__(RT_BLOCK) void k_finish(DCamera cam, DPool P, const uint32_t* tiles,
                                                      uint32_t tile0, uint32_t npixels, int shard_mode,
                                                      uint8_t* out, float* outf) {
-    for (uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x; lp < npixels; lp += gridDim.x * blockDim.x) {
+    __shared__ float stage[RT_BLOCK * FIN_ROW];
+    const uint32_t spp = (uint32_t)cam.spp;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < npixels; base += gridDim.x * blockDim.x) {
+        const uint32_t lp = base + threadIdx.x;
+        const uint32_t npx = min((uint32_t)RT_BLOCK, npixels - base);
+        F3 u = f3(0, 0, 0);
+        for (uint32_t j0 = 0; j0 < spp; j0 += FIN_CHUNK) {
+            const uint32_t cnt = min((uint32_t)FIN_CHUNK, spp - j0);
+            __syncthreads();
+            for (uint32_t e = threadIdx.x; e < npx * cnt; e += RT_BLOCK) {
+                uint32_t p = e / cnt, j = e - p * cnt;
+                float4 c = P.scol[(size_t)(base + p) * spp + j0 + j];
+                float* dst = stage + p * FIN_ROW + 3 * j;
+                dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+            }
+            __syncthreads();
+            if (lp < npixels) {
+                const float* src = stage + threadIdx.x * FIN_ROW;
+                uint32_t j = 0;
+                if (j0 == 0) { u = f3(src[0], src[1], src[2]); j = 1; }   // ave starts from the first sample, not from zero
+                for (; j < cnt; j++) u = u + f3(src[3 * j], src[3 * j + 1], src[3 * j + 2]);
+            }
+        }
+        if (lp >= npixels) continue;
         int x, y, px, py; uint32_t tile;
         pixel_of(tiles, tile0, lp, x, y, px, py, tile);
         if (x >= cam.width || y >= cam.height) continue;
-        const float4* c = P.scol + (size_t)lp * (uint32_t)cam.spp;
-        F3 u = f3(c[0]);
-        if (cam.spp > 1) {
-            for (int j = 1; j < cam.spp; j++) u = u + f3(c[j]);
-            u = u / (float)cam.spp;
-        }
+        if (spp > 1) u = u / (float)cam.spp;
         size_t at = shard_mode ? ((size_t)tile * RT_TILE_AREA + (size_t)py * RT_TILE_PX + px)
                                : ((size_t)y * cam.width + x);
         if (out) {
@@ -965,8 +1000,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_query(DScene S, int64_t n, const f
         F3 ro = f3(o[3 * ii], o[3 * ii + 1], o[3 * ii + 2]);
         F3 rd = f3(d[3 * ii], d[3 * ii + 1], d[3 * ii + 2]);
         float dm = dmax ? dmax[ii] : __builtin_inff();
-        int best; float best_d2;
-        trace<ACCEL, ANY>(S, lds, active, ro, rd, dm, best, best_d2, ts);
+        int best; float best_d2; HitUV uv;
+        trace<ACCEL, ANY>(S, lds, active, ro, rd, dm, best, best_d2, uv, ts);
         if (active) {
             prim_out[i] = best;
             if (d2_out) d2_out[i] = best >= 0 ? best_d2 : __builtin_inff();

@@ -124,6 +124,14 @@ __device__ inline void tri_load(const float4* __restrict__ t, F3& a, F3& ab, F3&
     ac = f3(q1.z, q1.w, q2.x);
 }
 
+// What a walk keeps of its winning candidate besides the primitive id and the squared
+// distance: for a triangle (float)beta and (float)gamma, for a sphere the float ray
+// parameter -- exactly the values the reference builds the hit point from (:329-330,
+// :246-255), so the hit record needs no second intersection test.
+struct HitUV {
+    float a, b;
+};
+
 // ---------------------------------------------------------------- hit record
 // Re-evaluates the winning primitive with the same arithmetic and writes the
 // Intersect fields the shading needs (src/raytrace.cpp:246-255, :329-387).
@@ -147,6 +155,36 @@ __device__ inline void make_hit(const DScene& S, F3 o, F3 d, double dd, int prim
         point = h.point;
         normal = tri_normal(S.tri_n + 3 * (size_t)t, (int)fbits(q2.z), d, h);
         mat = (int)fbits(q2.y);
+    }
+}
+
+// Same record from the values the walk kept.  Smooth triangles blend their normals with
+// the DOUBLE barycentrics (src/raytrace.cpp:344-357), so they are re-tested.
+__device__ inline void make_hit_uv(const DScene& S, F3 o, F3 d, int prim, HitUV uv, F3& point, F3& normal,
+                                   int& mat) {
+    if (prim < S.ns) {
+        float4 s = S.sph[prim];
+        point = o + (d * uv.a);
+        normal = norm3(point - f3(s));
+        mat = S.sph_mat[prim];
+    } else {
+        int t = prim - S.ns;
+        F3 a, ab, ac;
+        tri_load(S.tri + 3 * (size_t)t, a, ab, ac);
+        float4 q2 = S.tri[3 * (size_t)t + 2];
+        mat = (int)fbits(q2.y);
+        if (fbits(q2.z) == 0u) {
+            point = a + ((neg3(ab) * uv.a) + (neg3(ac) * uv.b));
+            F3 n0 = f3(S.tri_n[3 * (size_t)t]);
+            double ang = (double)dot3(n0, d);
+            normal = (ang > 0) ? neg3(n0) : n0;
+        } else {
+            TriHit h;
+            h.beta = h.gamma = 0; h.point = f3(0, 0, 0); h.d2 = 0;
+            tri_test(o, d, a, ab, ac, __builtin_inff(), h);
+            point = h.point;
+            normal = tri_normal(S.tri_n + 3 * (size_t)t, 1, d, h);
+        }
     }
 }
 
