@@ -96,7 +96,7 @@ static void free_scene(rt_ctx* c) {
     c->has_scene = false;
 }
 static void free_pool(rt_ctx* c) {
-    hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.loc);
+    hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.hd); hipFree(c->P.loc);
     hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.occl); hipFree(c->P.scol);
     hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr); hipFree(c->P.hit_base);
     hipFree(c->P.child_base); hipFree(c->P.blocksum); hipFree(c->P.hitlist); hipFree(c->P.wq);
@@ -178,6 +178,7 @@ static void compute_camera(const rt_scene_desc& s, DCamera& cam) {
     cam.blv = down * dot3(ptop, down);
     cam.width = s.width; cam.height = s.height; cam.spp = s.spp; cam.proj = s.proj;
     cam.seed = s.seed;
+    cam.inv_w = 1.0 / (double)s.width; cam.inv_h = 1.0 / (double)s.height;
 }
 
 // ---------------------------------------------------------------- scene upload
@@ -335,6 +336,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.d, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.hp, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.hn, capacity * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->P.hd, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.loc, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.cre, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.cra, capacity * sizeof(float4)));
@@ -408,7 +410,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         tm.mark(3);
         rtk_shadow(st, acc_s, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
         tm.mark(1);
-        rtk_shade(st, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks);
+        rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
         tm.mark(2);
         bound = std::min<uint64_t>(bound * 2, cap);
     }
@@ -484,7 +486,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                 hipEventRecord(ev[4 * g + 2], st);
                 rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
                 hipEventRecord(ev[4 * g + 3], st);
-                rtk_shade(st, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks);
+                rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
                 bound = std::min<uint64_t>(bound * 2, c->P.capacity);
             }
             DCounters hc;

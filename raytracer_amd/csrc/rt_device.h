@@ -55,7 +55,19 @@ struct DCamera {
     F3 urv, blv;      // right^ * dot(p2-p1, right^),  down^ * dot(p2-p1, down^)
     int width, height, spp, proj;
     uint32_t seed;
+    double inv_w, inv_h;   // 1.0 / width, 1.0 / height, correctly rounded (see rt_cdiv)
 };
+
+// a / b, correctly rounded, for a divisor whose reciprocal y = RN(1 / b) is at hand: two
+// fused residual corrections of a * y (Markstein's division; exact unless b's significand is
+// all ones or the quotient leaves the normal range, neither of which a film dimension or
+// 2^31 - 1 can cause).  Five multiply-adds instead of the ~12-instruction hardware sequence
+// with its quarter-rate reciprocal.
+__host__ __device__ inline double rt_cdiv(double a, double b, double y) {
+    double q = a * y;
+    q = __builtin_fma(__builtin_fma(-q, b, a), y, q);
+    return __builtin_fma(__builtin_fma(-q, b, a), y, q);
+}
 
 struct DScene {
     const float4* sph;       // [ns]  cx cy cz r
@@ -98,7 +110,8 @@ struct DPool {
     float4* cra;      // colour returned by the refraction child
     // per ray of the CURRENT generation (index = ray - generation start), rewritten every generation
     float4* hp;       // hit point xyz, w = primitive id (bits)           [hit rays only]
-    float4* hn;       // shading normal xyz, w = material id (bits)
+    float4* hn;       // shading normal xyz, w = material id | child slot << 31 (bits)
+    float4* hd;       // direction of the ray that hit, w = parent code (as in o.w)
     // per 64-ray group of the current generation: wave ballots and their prefix sums
     unsigned long long* mask_hit;    // ray hit something
     unsigned long long* mask_refl;   // hit spawns a reflection ray

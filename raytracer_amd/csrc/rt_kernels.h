@@ -13,8 +13,7 @@ void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks);
-void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
-               const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks);
+void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks);
 void rtk_finish(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles, uint32_t tile0,

@@ -497,14 +497,14 @@ __device__ inline void primary_ray(const DCamera& cam, int x, int y, int j, F3& 
         unsigned long long c = (((unsigned long long)y * (unsigned long long)cam.width +
                                  (unsigned long long)x) * (unsigned long long)cam.spp +
                                 (unsigned long long)j) * 2ull;
-        r1 = (double)(int)rt_jitter(cam.seed, c) / 2147483647;
-        r2 = (double)(int)rt_jitter(cam.seed, c + 1) / 2147483647;
+        r1 = rt_cdiv((double)(int)rt_jitter(cam.seed, c), 2147483647.0, 1.0 / 2147483647.0);
+        r2 = rt_cdiv((double)(int)rt_jitter(cam.seed, c + 1), 2147483647.0, 1.0 / 2147483647.0);
     } else {
         r1 = r2 = .5;
     }
-    int w = cam.width, h = cam.height;
-    F3 ur = cam.urv * (float)((double)x / w + (r1 / w));
-    F3 bl = cam.blv * (float)((double)y / h + (r2 / h));
+    const double w = (double)cam.width, h = (double)cam.height;
+    F3 ur = cam.urv * (float)(rt_cdiv((double)x, w, cam.inv_w) + rt_cdiv(r1, w, cam.inv_w));
+    F3 bl = cam.blv * (float)(rt_cdiv((double)y, h, cam.inv_h) + rt_cdiv(r2, h, cam.inv_h));
     F3 p = (ur + bl) + cam.p1;
     if (cam.proj == 1) { o = cam.pos; d = norm3(p); }
     else { o = p; d = cam.dir; }
@@ -617,7 +617,8 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc&
         F3 point, normal; int mat;
         make_hit_uv(S, o, d, best, uv, point, normal, mat);
         P.hp[i] = make_float4(point.x, point.y, point.z, bitsf((uint32_t)best));
-        P.hn[i] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat));
+        P.hn[i] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat | (R.slot << 31)));
+        P.hd[i] = make_float4(d.x, d.y, d.z, bitsf(R.parent));
         if (g + 1 <= S.max_depth) {   // deeper children are never traced (src/raytrace.cpp:132-135)
             const float4* M = S.mats + 4 * (size_t)mat;
             Spawn sp = spawn_of(f3(M[2]), f3(M[3]), M[1].w, d, normal);
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
 // generation are written at the offsets the scan assigned (or, past max_depth,
 // the background is added directly as evaluateRayTree :132-135 returns it
 // without tracing).
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters* C, int g) {
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
@@ -798,13 +799,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x) {
         const uint32_t i = P.hitlist[h];
         const uint32_t r = start + i;
-        float4 qp = P.hp[i], qn = P.hn[i];
-        RayRec R = load_ray(P, G, g, i, r);
-        uint32_t parent = R.parent;
-        F3 direct = R.d;
+        float4 qp = P.hp[i], qn = P.hn[i], qd = P.hd[i];
+        const uint32_t parent = fbits(qd.w), slot = fbits(qn.w) >> 31;
+        F3 direct = f3(qd);
         F3 point = f3(qp);
         F3 normal = f3(qn);
-        int mat = (int)fbits(qn.w);
+        int mat = (int)(fbits(qn.w) & 0x7FFFFFFFu);
         const float4* M = S.mats + 4 * (size_t)mat;
         float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
         F3 dif = f3(m1), spec = f3(m2), trans = f3(m3);
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters
             leaf = true;
         }
         if (leaf) {
-            deliver(P, g, parent, R.slot, f3(rval, gval, bval));
+            deliver(P, g, parent, slot, f3(rval, gval, bval));
             P.loc[r] = make_float4(rval, gval, bval, 0.0f);
             continue;
         }
@@ -1065,10 +1065,9 @@ void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
     else if (accel == 2) hipLaunchKernelGGL(k_shadow<2>, grid, block, 0, st, S, P, C, g);
     else hipLaunchKernelGGL(k_shadow<3>, grid, block, 0, st, S, P, C, g);
 }
-void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
-               const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks) {
-    GenSrc G{cam, tiles, tile0};
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, G, g);
+void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
+               int max_blocks) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
 }
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks) {
