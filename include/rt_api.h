@@ -44,7 +44,10 @@ enum { RT_LIGHT_AMBIENT = 0, RT_LIGHT_DIRECTIONAL = 1, RT_LIGHT_POINT = 2, RT_LI
 enum { RT_PROJ_ORTHO = 0, RT_PROJ_PERSP = 1 };
 /* Acceleration structure selection. */
 enum { RT_ACCEL_AUTO = 0, RT_ACCEL_BRUTE = 1, RT_ACCEL_LBVH = 2,
-       RT_ACCEL_LBVH_PACKET = 3 /* rt_query_rays only: force the wave-packet walk of the LBVH */ };
+       RT_ACCEL_LBVH_PACKET = 3 /* rt_query_rays only: force the wave-packet walk of the LBVH */,
+       RT_ACCEL_ALT_TREE = 16   /* rt_query_rays only, OR-ed to LBVH / LBVH_PACKET: walk the second
+                                   hierarchy (PLOC) that rt_load_scene built beside the Karras
+                                   one; available until the first render has chosen between them */ };
 
 /* One light: the fields of the reference's class Light (src/parse.h:188-195). */
 typedef struct rt_light {

@@ -69,6 +69,8 @@ struct rt_ctx {
     float4* d_tri = nullptr; float4* d_tri_n = nullptr;
     float4* d_mats = nullptr; DLight* d_lights = nullptr;
     float4* d_nodes = nullptr; int* d_prim_idx = nullptr; float4* d_leaf = nullptr;
+    // second hierarchy over the same leaves (PLOC), until calibration has picked one of the two
+    float4* d_nodes_alt = nullptr; int depth_alt = 0;
 
     // ray pool
     DPool P{};
@@ -90,9 +92,9 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c) {
     hipFree(c->d_sph); hipFree(c->d_sph_mat); hipFree(c->d_tri); hipFree(c->d_tri_n);
-    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
+    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_nodes_alt); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
     c->d_sph = nullptr; c->d_sph_mat = nullptr; c->d_tri = nullptr; c->d_tri_n = nullptr;
-    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_prim_idx = nullptr; c->d_leaf = nullptr;
+    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_nodes_alt = nullptr; c->d_prim_idx = nullptr; c->d_leaf = nullptr;
     c->has_scene = false;
 }
 static void free_pool(rt_ctx* c) {
@@ -272,10 +274,16 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     if (accel == RT_ACCEL_AUTO) accel = (S.n_prims > thr) ? RT_ACCEL_LBVH : RT_ACCEL_BRUTE;
     // the LBVH is also built when brute force renders, if rt_query_rays may ask for it
     if (S.n_prims >= 2) {
-        int root = 0;
-        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf, &root, &S.depth);
+        int radius = 16;                                     // RT_PLOC_RADIUS=0: Karras hierarchy only
+        if (const char* e = getenv("RT_PLOC_RADIUS")) radius = std::max(0, std::min(256, atoi(e)));
+        int depth_k = 0;
+        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf,
+                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt);
         if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
-        S.nodes = c->d_nodes; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = root;
+        S.nodes = c->d_nodes; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = 0; S.depth = depth_k;
+        if (getenv("RT_VERBOSE"))
+            fprintf(stderr, "[rt bvh] %d primitives; Karras depth %d; PLOC(radius %d) depth %d%s\n", S.n_prims, depth_k, radius,
+                    c->depth_alt, c->d_nodes_alt ? "" : " (not built)");
     } else {
         accel = RT_ACCEL_BRUTE;
     }
@@ -446,24 +454,45 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     return RT_OK;
 }
 
-// Picks, per ray generation, the faster of the two LBVH walks for the extend and the
-// shadow kernel by timing both on a sample of the frame: as many tiles as one batch holds,
-// evenly spaced over the rank's share of the film, all their samples.  Both walks give
-// bit-identical results, so only speed is at stake; the sample's pixels are discarded.
-// The sample is a whole batch on purpose: a small one measures latency, not throughput,
-// and picks the per-lane walk where the packet walk wins at scale.  Once per loaded scene.
+// Keeps one of the two hierarchies built at load time and frees the other.
+static void adopt_tree(rt_ctx* c, bool use_alt) {
+    if (!c->d_nodes_alt) return;
+    if (use_alt) {
+        std::swap(c->d_nodes, c->d_nodes_alt);
+        c->S.depth = c->depth_alt;
+    }
+    hipFree(c->d_nodes_alt);
+    c->d_nodes_alt = nullptr;
+    c->S.nodes = c->d_nodes;
+    c->S.root = 0;
+}
+
+// Picks the hierarchy (Karras or PLOC, when both were built) and, per ray generation, the
+// faster of the two LBVH walks for the extend and the shadow kernel, by timing them on a
+// sample of the frame: as many tiles as one batch holds, evenly spaced over the rank's
+// share of the film, all their samples.  Every combination gives bit-identical results, so
+// only speed is at stake; the sample's pixels are discarded.  The sample is a whole batch
+// on purpose: a small one measures latency, not throughput, and picks the per-lane walk
+// where the packet walk wins at scale.  Once per loaded scene.
 static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     c->tuned = true;
-    if (c->accel != RT_ACCEL_LBVH || c->forced_modes || c->tiles.empty()) return RT_OK;
-    const DScene& S = c->S;
+    if (c->accel != RT_ACCEL_LBVH || c->forced_modes || c->tiles.empty()) {
+        // no measurement: PLOC pays off on meshes, Karras on huge uniform clouds
+        adopt_tree(c, c->S.n_prims <= (1 << 20));
+        return RT_OK;
+    }
+    DScene& S = c->S;
     const uint32_t spp = (uint32_t)c->cam.spp;
     const uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
     const uint32_t total = (uint32_t)c->tiles.size();
     const int G = S.max_depth + 1;
+    const int ntrees = c->d_nodes_alt ? 2 : 1;
+    const float4* tree_nodes[2] = {c->d_nodes, c->d_nodes_alt};
+    const int tree_depth[2] = {S.depth, c->depth_alt};
     std::vector<hipEvent_t> ev((size_t)G * 4);
     for (auto& e : ev) hipEventCreate(&e);
     uint32_t* d_pick = nullptr;
-    float te[4][RT_MAX_GEN + 1] = {}, tsh[4][RT_MAX_GEN + 1] = {};
+    static float te[2][4][RT_MAX_GEN + 1], tsh[2][4][RT_MAX_GEN + 1];
     bool ok = false;
     uint32_t n = std::min(total, std::max(1u, tiles_per_batch));
     for (; !ok && n >= 1; n /= 2) {
@@ -474,48 +503,66 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         HIP_TRY(hipMemcpyAsync(d_pick, pick.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         const uint32_t nsamples = (uint32_t)(n * per_tile);
         ok = true;
-        for (int mode = 2; mode <= 3 && ok; mode++) {
-            hipStream_t st = c->stream;
-            rtk_init_counters(st, c->d_counters, nsamples, c->P, G);
-            uint64_t bound = nsamples;
-            for (int g = 0; g < G; g++) {
-                hipEventRecord(ev[4 * g + 0], st);
-                rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks);
-                hipEventRecord(ev[4 * g + 1], st);
-                rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
-                hipEventRecord(ev[4 * g + 2], st);
-                rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
-                hipEventRecord(ev[4 * g + 3], st);
-                rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
-                bound = std::min<uint64_t>(bound * 2, c->P.capacity);
-            }
-            DCounters hc;
-            if (hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { ok = false; n = 0; break; }
-            if (hc.overflow) { ok = false; break; }      // sample does not fit the pool: halve it
-            for (int g = 0; g < G; g++) {
-                hipEventElapsedTime(&te[mode][g], ev[4 * g + 0], ev[4 * g + 1]);
-                hipEventElapsedTime(&tsh[mode][g], ev[4 * g + 2], ev[4 * g + 3]);
+        for (int t = 0; t < ntrees && ok; t++) {
+            S.nodes = tree_nodes[t]; S.depth = tree_depth[t]; S.root = 0;
+            for (int mode = 2; mode <= 3 && ok; mode++) {
+                hipStream_t st = c->stream;
+                rtk_init_counters(st, c->d_counters, nsamples, c->P, G);
+                uint64_t bound = nsamples;
+                for (int g = 0; g < G; g++) {
+                    hipEventRecord(ev[4 * g + 0], st);
+                    rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks);
+                    hipEventRecord(ev[4 * g + 1], st);
+                    rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
+                    hipEventRecord(ev[4 * g + 2], st);
+                    rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
+                    hipEventRecord(ev[4 * g + 3], st);
+                    rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
+                    bound = std::min<uint64_t>(bound * 2, c->P.capacity);
+                }
+                DCounters hc;
+                if (hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) { ok = false; n = 0; break; }
+                if (hc.overflow) { ok = false; break; }      // sample does not fit the pool: halve it
+                for (int g = 0; g < G; g++) {
+                    hipEventElapsedTime(&te[t][mode][g], ev[4 * g + 0], ev[4 * g + 1]);
+                    hipEventElapsedTime(&tsh[t][mode][g], ev[4 * g + 2], ev[4 * g + 3]);
+                }
             }
         }
         if (ok) break;
     }
+    S.nodes = tree_nodes[0]; S.depth = tree_depth[0];
     for (auto& e : ev) hipEventDestroy(e);
     hipFree(d_pick);
     if (ok) {
+        float best_total[2] = {0, 0};
+        for (int t = 0; t < ntrees; t++)
+            for (int g = 0; g < G; g++)
+                best_total[t] += std::min(te[t][2][g], te[t][3][g]) + std::min(tsh[t][2][g], tsh[t][3][g]);
+        int t = (ntrees == 2 && best_total[1] < best_total[0]) ? 1 : 0;
+        if (const char* e = getenv("RT_TREE")) {             // "karras" / "ploc": override the measurement
+            if (!strcmp(e, "karras")) t = 0;
+            else if (!strcmp(e, "ploc") && ntrees == 2) t = 1;
+        }
+        adopt_tree(c, t == 1);
         for (int g = 0; g < G; g++) {
-            c->mode_extend[g] = te[3][g] <= te[2][g] ? 3 : 2;
-            c->mode_shadow[g] = tsh[3][g] <= tsh[2][g] ? 3 : 2;
+            c->mode_extend[g] = te[t][3][g] <= te[t][2][g] ? 3 : 2;
+            c->mode_shadow[g] = tsh[t][3][g] <= tsh[t][2][g] ? 3 : 2;
         }
         if (getenv("RT_VERBOSE")) {
-            fprintf(stderr, "[rt calibrate] %u tiles; extend (lane/packet ms):", n);
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, te[2][g], te[3][g], c->mode_extend[g] == 3 ? 'P' : 'L');
+            fprintf(stderr, "[rt calibrate] %u tiles; traversal ms Karras %.3f", n, best_total[0]);
+            if (ntrees == 2) fprintf(stderr, ", PLOC %.3f", best_total[1]);
+            fprintf(stderr, " -> %s; extend (lane/packet ms):", t ? "PLOC" : "Karras");
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, te[t][2][g], te[t][3][g], c->mode_extend[g] == 3 ? 'P' : 'L');
             fprintf(stderr, "; shadow:");
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, tsh[2][g], tsh[3][g], c->mode_shadow[g] == 3 ? 'P' : 'L');
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, tsh[t][2][g], tsh[t][3][g], c->mode_shadow[g] == 3 ? 'P' : 'L');
             fprintf(stderr, "\n");
         }
-    } else if (getenv("RT_VERBOSE")) {
-        fprintf(stderr, "[rt calibrate] no sample fitted the ray pool: keeping the packet walk everywhere\n");
+    } else {
+        adopt_tree(c, c->S.n_prims <= (1 << 20));
+        if (getenv("RT_VERBOSE"))
+            fprintf(stderr, "[rt calibrate] no sample fitted the ray pool: keeping the packet walk everywhere\n");
     }
     return RT_OK;
 }
@@ -682,7 +729,13 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
                              int any_hit, int accel, int32_t* prim_out, float* dist2_out) {
     if (!c || n < 0 || !o || !d || !prim_out) return RT_ERR_INVALID;
     if (!c->has_scene) return RT_ERR_NO_SCENE;
+    const bool alt = (accel & RT_ACCEL_ALT_TREE) != 0;
+    accel &= ~RT_ACCEL_ALT_TREE;
     if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH && accel != RT_ACCEL_LBVH_PACKET) return RT_ERR_INVALID;
+    if (alt && (accel == RT_ACCEL_BRUTE || !c->d_nodes_alt)) {
+        rt_set_error("no second hierarchy is held (none was built, or a render has already chosen)");
+        return RT_ERR_UNSUPPORTED;
+    }
     if (accel != RT_ACCEL_BRUTE && !c->S.nodes) { rt_set_error("scene has fewer than 2 primitives: no LBVH"); return RT_ERR_UNSUPPORTED; }
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -698,7 +751,9 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     Q_TRY(hipMemcpyAsync(d_o, o, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     Q_TRY(hipMemcpyAsync(d_d, d, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (dmax) Q_TRY(hipMemcpyAsync(d_m, dmax, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    rtk_query(c->stream, accel, any_hit, c->S, n, d_o, d_d, d_m, d_p, d_d2);
+    DScene Sq = c->S;
+    if (alt) { Sq.nodes = c->d_nodes_alt; Sq.depth = c->depth_alt; Sq.root = 0; }
+    rtk_query(c->stream, accel, any_hit, Sq, n, d_o, d_d, d_m, d_p, d_d2);
     Q_TRY(hipGetLastError());
     Q_TRY(hipMemcpyAsync(prim_out, d_p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (dist2_out) Q_TRY(hipMemcpyAsync(dist2_out, d_d2, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));

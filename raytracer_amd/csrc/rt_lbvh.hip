@@ -208,12 +208,190 @@ __global__ void k_depth(const int* parent_inner, const int* parent_leaf, int n, 
     if ((threadIdx.x & 63) == 0 && dpt > 0) atomicMax(out, (uint32_t)dpt);
 }
 
+// ---------------------------------------------------------------- PLOC
+// Parallel locally-ordered clustering (Meister & Bittner 2018): bottom-up agglomeration
+// over the Morton-sorted sequence.  Every round, each cluster looks RADIUS places to either
+// side for the neighbour whose union with it has the smallest surface area; two clusters
+// that pick each other merge into a new inner node, which takes the place of the left
+// one; the sequence is compacted and the round repeats until one cluster is left.
+// The trees come out close to a surface-area-heuristic build (fewer node visits per ray
+// than the Karras hierarchy over the same codes) at the cost of ~40 small rounds.
+// Ties go to the lower index, which makes the globally cheapest pair mutual, so every
+// round merges at least once.  Node ids follow the order of creation (prefix sums, no
+// atomics): deterministic, and nodes of one round are contiguous in Morton order.
+// A cluster is two float4: (lo.xyz, ref) and (hi.xyz, depth of its subtree).
+__global__ void k_ploc_init(const Box* boxes, const uint32_t* sorted, int n, float4* lo, float4* hi) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Box b = boxes[sorted[j]];
+    lo[j] = make_float4(b.lo[0], b.lo[1], b.lo[2], __int_as_float(~j));
+    hi[j] = make_float4(b.hi[0], b.hi[1], b.hi[2], __int_as_float(0));
+}
+
+__global__ void k_ploc_nn(const float4* __restrict__ lo, const float4* __restrict__ hi, int n, int radius, int* nn) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 l = lo[i], h = hi[i];
+    unsigned long long best = ~0ull;
+    const int j0 = max(0, i - radius), j1 = min(n - 1, i + radius);
+    for (int j = j0; j <= j1; j++) {
+        if (j == i) continue;
+        const float4 a = lo[j], b = hi[j];
+        float dx = fmaxf(h.x, b.x) - fminf(l.x, a.x);
+        float dy = fmaxf(h.y, b.y) - fminf(l.y, a.y);
+        float dz = fmaxf(h.z, b.z) - fminf(l.z, a.z);
+        float area = dx * dy + dy * dz + dz * dx;       // >= 0 (or NaN): its bit pattern orders like the value
+        unsigned long long key = ((unsigned long long)__float_as_uint(area) << 32) | (unsigned)j;
+        best = key < best ? key : best;
+    }
+    nn[i] = (int)(unsigned)best;
+}
+
+// flags[i] = (survives the round) | (is the left partner of a merge) << 32
+__global__ void k_ploc_flag(const int* nn, int n, unsigned long long* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int j = nn[i];
+    bool mutual = nn[j] == i;
+    unsigned long long valid = !(mutual && i > j), merge = (mutual && i < j);
+    flags[i] = valid | (merge << 32);
+}
+
+__global__ void k_ploc_merge(const float4* lo, const float4* hi, const int* nn, const unsigned long long* flags,
+                             const unsigned long long* pref, int n, int node_base, float4* nodes,
+                             int* parent, int* inner, float4* lo2, float4* hi2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long f = flags[i];
+    if (!(f & 1ull)) return;
+    const unsigned long long p = pref[i];
+    const int pos = (int)(unsigned)p;
+    float4 l = lo[i], h = hi[i];
+    if (f >> 32) {
+        const int k = node_base + (int)(p >> 32);
+        const int j = nn[i];
+        const float4 a = lo[j], b = hi[j];
+        float4* nd = nodes + 4 * (size_t)k;
+        nd[0] = make_float4(l.x, h.x, l.y, h.y);
+        nd[1] = make_float4(l.z, h.z, a.x, b.x);
+        nd[2] = make_float4(a.y, b.y, a.z, b.z);
+        nd[3] = make_float4(l.w, a.w, 0.0f, 0.0f);                       // the two child references
+        const int c0 = __float_as_int(l.w), c1 = __float_as_int(a.w);
+        int below = 1;                                                    // inner nodes of this subtree
+        if (c0 >= 0) { parent[c0] = 2 * k; below += inner[c0]; }
+        if (c1 >= 0) { parent[c1] = 2 * k + 1; below += inner[c1]; }
+        inner[k] = below;
+        parent[k] = -1;                                                   // until a later round adopts it
+        int depth = max(__float_as_int(h.w), __float_as_int(b.w)) + 1;
+        l = make_float4(fminf(l.x, a.x), fminf(l.y, a.y), fminf(l.z, a.z), __int_as_float(k));
+        h = make_float4(fmaxf(h.x, b.x), fmaxf(h.y, b.y), fmaxf(h.z, b.z), __int_as_float(depth));
+    }
+    lo2[pos] = l;
+    hi2[pos] = h;
+}
+
+// Depth-first (pre-order) position of every node: root 0, a left child right after its
+// parent, a right child after the whole left subtree.  A walk that descends reads forward
+// through memory, which is what keeps a tree far larger than the caches fast; the ids the
+// rounds hand out put the nodes of one subtree a round apart instead.
+__global__ void k_ploc_dfs(const float4* nodes, const int* parent, const int* inner, int m, int* pos) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m) return;
+    int at = 0;
+    for (int link = parent[v]; link >= 0; ) {
+        const int a = link >> 1;
+        at += 1;
+        if (link & 1) {                                   // came up from the right: skip the left sibling's subtree
+            const int left = __float_as_int(nodes[4 * (size_t)a + 3].x);
+            if (left >= 0) at += inner[left];
+        }
+        link = parent[a];
+    }
+    pos[v] = at;
+}
+__global__ void k_ploc_place(const float4* nodes, const int* pos, int m, float4* out) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m) return;
+    const float4* src = nodes + 4 * (size_t)v;
+    float4 refs = src[3];
+    int c0 = __float_as_int(refs.x), c1 = __float_as_int(refs.y);
+    if (c0 >= 0) c0 = pos[c0];
+    if (c1 >= 0) c1 = pos[c1];
+    float4* dst = out + 4 * (size_t)pos[v];
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    dst[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.0f, 0.0f);
+}
+
+// boxes / sorted: padded primitive boxes and the Morton order.  Fills nodes[n-1] (root = node 0), depth.
+static int ploc_build(hipStream_t st, const Box* boxes, const uint32_t* sorted, int n, int radius, float4* nodes_out,
+                      int* root, int* depth) {
+    float4 *lo[2] = {nullptr, nullptr}, *hi[2] = {nullptr, nullptr}, *nodes = nullptr;
+    int *nn = nullptr, *parent = nullptr, *inner = nullptr, *pos = nullptr;
+    unsigned long long *flags = nullptr, *pref = nullptr; void* tmp = nullptr;
+    auto cleanup = [&]() {
+        void* ptrs[] = {lo[0], lo[1], hi[0], hi[1], nodes, nn, parent, inner, pos, flags, pref, tmp};
+        for (void* p : ptrs) (void)hipFree(p);
+    };
+#define P_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return (int)e_; } } while (0)
+    for (int k = 0; k < 2; k++) { P_TRY(hipMalloc(&lo[k], (size_t)n * sizeof(float4))); P_TRY(hipMalloc(&hi[k], (size_t)n * sizeof(float4))); }
+    P_TRY(hipMalloc(&nn, (size_t)n * sizeof(int)));
+    P_TRY(hipMalloc(&nodes, (size_t)(n - 1) * 4 * sizeof(float4)));
+    P_TRY(hipMalloc(&parent, (size_t)n * sizeof(int))); P_TRY(hipMalloc(&inner, (size_t)n * sizeof(int)));
+    P_TRY(hipMalloc(&pos, (size_t)n * sizeof(int)));
+    P_TRY(hipMalloc(&flags, (size_t)n * 8)); P_TRY(hipMalloc(&pref, (size_t)n * 8));
+    size_t tmp_bytes = 0;
+    P_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pref, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
+    P_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+    hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, st, boxes, sorted, n, lo[0], hi[0]);
+    int count = n, node_base = 0, cur = 0, rounds = 0;
+    while (count > 1) {
+        if (++rounds > 4096) { cleanup(); return (int)hipErrorUnknown; }
+        dim3 grid((count + 255) / 256), block(256);
+        hipLaunchKernelGGL(k_ploc_nn, grid, block, 0, st, lo[cur], hi[cur], count, radius, nn);
+        hipLaunchKernelGGL(k_ploc_flag, grid, block, 0, st, nn, count, flags);
+        P_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, flags, pref, 0ull, (size_t)count, rocprim::plus<unsigned long long>(), st));
+        hipLaunchKernelGGL(k_ploc_merge, grid, block, 0, st, lo[cur], hi[cur], nn, flags, pref, count, node_base, nodes,
+                           parent, inner, lo[cur ^ 1], hi[cur ^ 1]);
+        unsigned long long last[2];
+        P_TRY(hipMemcpyAsync(&last[0], flags + (count - 1), 8, hipMemcpyDeviceToHost, st));
+        P_TRY(hipMemcpyAsync(&last[1], pref + (count - 1), 8, hipMemcpyDeviceToHost, st));
+        P_TRY(hipStreamSynchronize(st));
+        unsigned long long tot = last[0] + last[1];
+        int survivors = (int)(unsigned)tot, merges = (int)(tot >> 32);
+        if (merges < 1 || survivors != count - merges) { cleanup(); return (int)hipErrorUnknown; }
+        node_base += merges;
+        count = survivors;
+        cur ^= 1;
+    }
+    float4 top[2];
+    P_TRY(hipMemcpyAsync(&top[0], lo[cur], sizeof(float4), hipMemcpyDeviceToHost, st));
+    P_TRY(hipMemcpyAsync(&top[1], hi[cur], sizeof(float4), hipMemcpyDeviceToHost, st));
+    P_TRY(hipStreamSynchronize(st));
+    int r, dpt;
+    memcpy(&r, &top[0].w, 4); memcpy(&dpt, &top[1].w, 4);
+    if (node_base != n - 1 || r != n - 2) { cleanup(); return (int)hipErrorUnknown; }   // the last node made is the root
+    hipLaunchKernelGGL(k_ploc_dfs, dim3((n - 1 + 255) / 256), dim3(256), 0, st, nodes, parent, inner, n - 1, pos);
+    hipLaunchKernelGGL(k_ploc_place, dim3((n - 1 + 255) / 256), dim3(256), 0, st, nodes, pos, n - 1, nodes_out);
+    P_TRY(hipGetLastError());
+    P_TRY(hipStreamSynchronize(st));
+    *root = 0; *depth = dpt;
+    cleanup();
+#undef P_TRY
+    return (int)hipSuccess;
+}
+
 #define L_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(vals2); (void)hipFree(leaf); return (int)e_; } } while (0)
 
+// Builds the Karras hierarchy (nodes_out, at most 95 deep) and, when ploc_radius > 0, a PLOC
+// hierarchy over the same Morton order (ploc_out; nullptr if it failed or came out deeper
+// than the 64-entry stacks of the fast walks allow).  Both share the leaf records and have
+// their root at node 0; which one traverses faster depends on the scene and is measured
+// by the caller.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
-              int** prim_idx_out, float4** leaf_out, int* root, int* depth) {
+              int** prim_idx_out, float4** leaf_out, int* depth, int ploc_radius, float4** ploc_out,
+              int* ploc_depth) {
     int n = ns + nt;
-    *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *root = 0;
+    *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *ploc_out = nullptr; *ploc_depth = 0;
     if (n < 2) return (int)hipErrorInvalidValue;
     Box* boxes = nullptr; uint32_t* scene = nullptr;
     unsigned long long *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;
@@ -243,19 +421,30 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     L_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, st));
     L_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
     L_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, st));
+    hipLaunchKernelGGL(k_leaves, dim3(blocks), dim3(256), 0, st, sph, ns, tri, vals2, n, leaf);
     hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, st, keys2, n, child, pin, plf);
     hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, boxes, vals2, n, child, pin, plf, flags, nodes);
-    hipLaunchKernelGGL(k_leaves, dim3(blocks), dim3(256), 0, st, sph, ns, tri, vals2, n, leaf);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, st, pin, plf, n, scene + 6);
-    L_TRY(hipGetLastError());
     uint32_t dpt = 0;
     L_TRY(hipMemcpyAsync(&dpt, scene + 6, sizeof(dpt), hipMemcpyDeviceToHost, st));
     L_TRY(hipStreamSynchronize(st));
     *depth = (int)dpt;
+    if (ploc_radius > 0) {
+        float4* pn = nullptr;
+        int r = 0, d = 0;
+        if (hipMalloc(&pn, (size_t)(n - 1) * 4 * sizeof(float4)) == hipSuccess &&
+            ploc_build(st, boxes, vals2, n, ploc_radius, pn, &r, &d) == (int)hipSuccess && d <= 64) {
+            *ploc_out = pn; *ploc_depth = d;
+        } else {
+            (void)hipFree(pn);
+            (void)hipGetLastError();
+        }
+    }
+    L_TRY(hipGetLastError());
+    L_TRY(hipStreamSynchronize(st));
     cleanup();
     *nodes_out = nodes;
     *prim_idx_out = (int*)vals2;   // sorted primitive ids, kept by the caller
     *leaf_out = leaf;
-    *root = 0;
     return (int)hipSuccess;
 }

@@ -77,12 +77,17 @@ def test_primary_rays_and_closest_hits_known_answers(oracle, tracer, kat, key, s
     assert np.array_equal(bits(d), bits(kat[f"ray_{key}_d"]))
     ref_hit = kat[f"hit_{key}"]
     want_prim, want_d2 = oracle.intersect_many(scene, o, d)
-    for accel in (ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+    for accel in (ra.RT_ACCEL_BRUTE,) + TREE_WALKS:
         prim, d2 = tracer.query_rays(o, d, accel=accel)
         assert np.array_equal(prim >= 0, ref_hit[:, 0] != 0)
         assert np.array_equal(prim, want_prim)
         hit = prim >= 0
         assert np.array_equal(d2[hit].astype(np.float64), ref_hit[hit, 4])   # reference dist (squared)
+
+
+# every walk of every hierarchy: Karras per-lane / packet, PLOC per-lane / packet
+TREE_WALKS = (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET,
+              ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_PACKET | ra.RT_ACCEL_ALT_TREE)
 
 
 def _random_rays(scene, n, rng):
@@ -110,7 +115,7 @@ def test_lbvh_equals_brute_force_on_random_rays(tracer, name):
     o, d = _random_rays(scene, n, rng)
     pb, db = tracer.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
     assert (pb >= 0).mean() > 0.2, "ray generator barely hits the scene"
-    for accel in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+    for accel in TREE_WALKS:
         pl, dl = tracer.query_rays(o, d, accel=accel)
         assert np.array_equal(pb, pl), f"accel {accel}: {(pb != pl).sum()} of {n} closest hits differ"
         assert np.array_equal(bits(db), bits(dl))
@@ -118,7 +123,7 @@ def test_lbvh_equals_brute_force_on_random_rays(tracer, name):
     dmax = np.where(rng.random(n) < 0.5, db * rng.uniform(0.5, 1.5, n).astype(np.float32), np.float32(np.inf)).astype(np.float32)
     dmax[~np.isfinite(dmax)] = np.inf
     ab, _ = tracer.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_BRUTE)
-    for accel in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+    for accel in TREE_WALKS:
         al, _ = tracer.query_rays(o, d, dmax=dmax, any_hit=True, accel=accel)
         assert np.array_equal(ab >= 0, al >= 0)
 
@@ -199,10 +204,23 @@ def test_synthetic_scene_lbvh_equals_brute_force(tracer):
     o, d = _random_rays(scene, 20_000, np.random.default_rng(11))
     pb, db = tracer.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
     assert (pb >= 0).mean() > 0.2
-    for accel in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+    for accel in TREE_WALKS:
         pl, dl = tracer.query_rays(o, d, accel=accel)
         assert np.array_equal(pb, pl), f"accel {accel}: {(pb != pl).sum()} closest hits differ"
         assert np.array_equal(bits(db), bits(dl))
+
+
+def test_both_hierarchies_render_the_same_image(tracer, monkeypatch):
+    """The first render picks Karras or PLOC by timing; force each in turn and compare."""
+    scene = load_scene("dragon").copy(width=192, height=128, spp=2)
+    monkeypatch.setenv("RT_TREE", "karras")
+    tracer.load_scene(scene)
+    rgb_k, f_k, st_k = tracer.render(want_float=True)
+    monkeypatch.setenv("RT_TREE", "ploc")
+    tracer.load_scene(scene)
+    rgb_p, f_p, st_p = tracer.render(want_float=True)
+    assert np.array_equal(rgb_k, rgb_p) and np.array_equal(bits(f_k), bits(f_p))
+    assert st_k.rays == st_p.rays
 
 
 def test_edge_cases(tracer):
