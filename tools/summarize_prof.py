@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output directories into small, commit-able text files.
 
-  python tools/summarize_prof.py <gpurun_out/prof dir> <profiles/prefix>
+  python tools/summarize_prof.py <gpurun_out/prof dir> <profiles/prefix> [workload]
 
 Reads <dir>/*_trace/**/_kernel_stats.csv (kernel-trace --stats) and every
 <dir>/*/**/_counter_collection.csv (one --pmc pass each) and writes
@@ -63,6 +63,22 @@ def main():
         if "SQ_ACTIVE_INST_VALU" in cs and "SQ_BUSY_CYCLES" in cs:
             res[k]["valu_active_per_wave_cycle"] = cs["SQ_ACTIVE_INST_VALU"][0] / max(1.0, cs["SQ_WAVE_CYCLES"][0])
     json.dump(res, open(prefix + "_pmc.json", "w"), indent=1, sort_keys=True)
+    if len(sys.argv) > 3:
+        # HBM bytes per launch of the traversal kernels (the variant launched most), for bench.py's
+        # roofline.traffic: corrected FETCH_SIZE (x2, an upper bound for narrow accesses) + WRITE_SIZE
+        tpath = os.path.join(os.path.dirname(prefix) or ".", "hbm_traffic.json")
+        table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        entry = {}
+        for base in ("k_extend", "k_shadow"):
+            cands = [(v["FETCH_SIZE"]["dispatches"], k) for k, v in res.items()
+                     if k.startswith(base) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+            if cands:
+                k = max(cands)[1]
+                entry[base] = round(res[k]["hbm_read_bytes_corrected"]["mean_per_dispatch"] +
+                                    res[k]["hbm_write_bytes"]["mean_per_dispatch"])
+                entry[base + "_variant"] = k
+        table[sys.argv[3]] = entry
+        json.dump(table, open(tpath, "w"), indent=1, sort_keys=True)
     print(open(prefix + "_kernel_stats.csv").read() if os.path.exists(prefix + "_kernel_stats.csv") else "")
     print(json.dumps({k: {c: (round(v["mean_per_dispatch"], 1) if isinstance(v, dict) else round(v, 4)) for c, v in cs.items()}
                       for k, cs in res.items()}, indent=1))
