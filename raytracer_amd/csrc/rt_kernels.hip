@@ -635,6 +635,132 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc&
     }
 }
 
+#ifndef REFILL_GROUPS
+#define REFILL_GROUPS 8
+#endif
+#ifndef REFILL_MIN
+#define REFILL_MIN 16
+#endif
+#define LANE_DONE ((int)0x80000000)   // ~(2^31 - 1): never a leaf slot
+
+
+// Closest-hit walk with lane refill (see shadow_chunk for the idea): a wave owns `n` consecutive
+// rays [first, first + n) of the generation, n <= REFILL_GROUPS * 64 and first a multiple
+// of 64.  A lane whose walk has ended waits until REFILL_MIN lanes have, then those lanes
+// write their hit (or miss) records together and take the next rays of the chunk.  Rays
+// are finished out of order, so the three ballot masks of each 64-ray group are put
+// together at the end from one flag byte per ray kept in LDS (`flags`, this wave's own).
+__device__ inline void extend_chunk(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
+                                    uint32_t first, uint32_t n, uint8_t* flags, TraceStats& ts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const v4f* nodes = (const v4f*)S.nodes;
+    enum { IDLE = 0, WALK = 1, FIN = 2 };
+    uint32_t next = 64, k = lane;
+    int state = IDLE;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
+    uint32_t parent = 0, slot = 0;
+    bool valid = false;
+    float tmax = 0, best_d2 = 0;
+    double dd = 1;
+    SlabRay R = slab_ray(o, d);
+    int cur = LANE_DONE, sp = 0, best = -1;
+    HitUV uv; uv.a = 0; uv.b = 0;
+    int stack[LBVH_STACK];
+    auto begin = [&](uint32_t rel) {
+        RayRec rr = load_ray(P, G, g, first + rel, start + first + rel);
+        o = rr.o; d = rr.d; parent = rr.parent; slot = rr.slot; valid = rr.valid;
+        best = -1; best_d2 = __builtin_inff(); uv.a = 0; uv.b = 0;
+        dd = (double)dot3(d, d);
+        R = slab_ray(o, d);
+        tmax = __builtin_inff();
+        cur = S.root; sp = 0;
+        state = valid ? WALK : FIN;
+    };
+    if (k < n) begin(k);
+    while (true) {
+        if (ballot64(state != IDLE) == 0ull) break;
+        if (state == WALK) {
+            if (cur >= 0) {
+                const v4f* nd = nodes + 4 * (size_t)cur;
+                v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                ts.nodes++; ts.lane_nodes++;
+                float tn0, tn1;
+                bool h0, h1;
+                box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
+                int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+                if (h0 && h1) {
+                    const bool swap = tn1 < tn0;
+                    if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
+                    cur = swap ? c1 : c0;
+                } else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp > 0) cur = stack[--sp];
+                else state = FIN;
+            } else {
+                const float4* lf = S.leaf + 3 * (size_t)(~cur);
+                float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
+                int prim = (int)fbits(l2.y);
+                if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
+                ts.lane_prims++;
+                float d2 = 0;
+                HitUV cand;
+                if (leaf_test(o, d, dd, l0, l1, l2, __builtin_inff(), d2, cand)) {
+                    if (best < 0 || d2 < best_d2 || (d2 == best_d2 && prim < best)) {
+                        best = prim; best_d2 = d2; uv = cand;
+                        tmax = slab_tmax(R, d2);
+                    }
+                }
+                if (sp > 0) cur = stack[--sp];
+                else state = FIN;
+            }
+        }
+        const unsigned long long fin = ballot64(state == FIN);
+        if (__popcll(fin) >= REFILL_MIN || ballot64(state == WALK) == 0ull) {
+            if (state == FIN) {
+                const uint32_t i = first + k, r = start + i;
+                uint32_t bits = 0;
+                if (valid && best >= 0) {
+                    F3 point, normal; int mat;
+                    make_hit_uv(S, o, d, best, uv, point, normal, mat);
+                    P.hp[i] = make_float4(point.x, point.y, point.z, bitsf((uint32_t)best));
+                    P.hn[i] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat | (slot << 31)));
+                    P.hd[i] = make_float4(d.x, d.y, d.z, bitsf(parent));
+                    bits = 1;
+                    if (g + 1 <= S.max_depth) {
+                        const float4* M = S.mats + 4 * (size_t)mat;
+                        Spawn spn = spawn_of(f3(M[2]), f3(M[3]), M[1].w, d, normal);
+                        bits |= (spn.refl ? 2u : 0u) | (spn.refr ? 4u : 0u);
+                    }
+                } else {
+                    if (valid) deliver(P, g, parent, slot, S.bg);
+                    P.loc[r] = make_float4(0, 0, 0, 0);
+                }
+                flags[k] = (uint8_t)bits;
+                state = IDLE;
+            }
+            const unsigned long long idle = ballot64(state == IDLE);
+            if (next < n) {
+                if (state == IDLE) {
+                    uint32_t rel = next + (uint32_t)__popcll(idle & below);
+                    if (rel < n) { k = rel; begin(k); }
+                }
+                next += (uint32_t)__popcll(idle);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (uint32_t base = 0; base < n; base += 64) {
+        uint32_t f = (base + lane < n) ? flags[base + lane] : 0u;
+        unsigned long long mh = ballot64(f & 1u), m1 = ballot64(f & 2u), m2 = ballot64(f & 4u);
+        if (lane == 0) {
+            uint32_t grp = (first + base) >> 6;
+            P.mask_hit[grp] = mh; P.mask_refl[grp] = m1; P.mask_refr[grp] = m2;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 template <int ACCEL>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
@@ -646,6 +772,23 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
     if (ACCEL == 1) {   // block-wide LDS staging: the whole block moves together
         for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
             extend_one<ACCEL>(S, P, G, g, start, count, base + threadIdx.x, lds, ts);
+    } else if (ACCEL == 2) {
+        __shared__ uint8_t flags[RT_BLOCK / 64][REFILL_GROUPS * 64];
+        const uint64_t groups = ((uint64_t)count + 63) >> 6;
+        const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+        uint64_t per = groups / (waves * 4);
+        per = per < 1 ? 1 : (per > REFILL_GROUPS ? REFILL_GROUPS : per);
+        const uint32_t span = (uint32_t)per << 6;
+        if (per == 1) {      // too little work to refill from: plain 64-ray groups
+            for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, groups, [&](uint64_t grp) {
+                extend_one<ACCEL>(S, P, G, g, start, count, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
+            });
+        } else {
+            for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + span - 1) / span, [&](uint64_t c) {
+                const uint32_t first = (uint32_t)c * span;
+                extend_chunk(S, P, G, g, start, first, min(span, count - first), flags[threadIdx.x >> 6], ts);
+            });
+        }
     } else {
         for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + 63) >> 6, [&](uint64_t grp) {
             extend_one<ACCEL>(S, P, G, g, start, count, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
@@ -754,6 +897,88 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int
     }
 }
 
+// ---------------------------------------------------------------- per-lane any-hit walk with lane refill
+// Incoherent shadow rays differ wildly in length: one hits the first box it enters, its
+// neighbour crosses the whole scene.  Walking 64 of them to the end leaves most lanes idle
+// most of the time.  Here a wave owns a chunk of up to REFILL_GROUPS x 64 consecutive work
+// items; a lane that has its answer stores it and, once REFILL_MIN lanes are idle, every
+// idle lane takes the next item of the chunk (ballot + prefix count, no atomics), so the
+// wave stays full until the chunk runs out.  One loop iteration = one node or one leaf per
+// lane, exactly the step of lbvh_trace<true>.
+__device__ inline void shadow_chunk(const DScene& S, const DPool& P, uint64_t first, uint64_t end, TraceStats& ts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const v4f* nodes = (const v4f*)S.nodes;
+    const uint32_t nl = (uint32_t)S.nl;
+    const uint32_t count = (uint32_t)(end - first);
+    uint32_t next = 64;                  // wave-uniform: first item of the chunk not handed out yet
+    uint32_t k = lane;                   // this lane's item, relative to `first`
+    bool alive = k < count;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
+    float dmax = 0, tmax = 0;
+    double dd = 1;
+    SlabRay R = slab_ray(o, d);
+    int cur = LANE_DONE, sp = 0;
+    int stack[LBVH_STACK];
+    auto start = [&](uint32_t rel) {
+        const uint64_t item = first + rel;
+        uint32_t h = (uint32_t)(item / nl);
+        int j = (int)(item - (uint64_t)h * nl);
+        o = f3(P.hp[P.hitlist[h]]);
+        light_dir(S.lights[j], o, d, dmax);
+        dd = (double)dot3(d, d);
+        R = slab_ray(o, d);
+        tmax = slab_tmax(R, dmax);
+        cur = S.root;
+        sp = 0;
+    };
+    if (alive) start(k);
+    while (ballot64(alive) != 0ull) {
+        if (alive) {
+            int verdict = -1;            // 0: reaches the light, 1: occluded
+            if (cur >= 0) {
+                const v4f* nd = nodes + 4 * (size_t)cur;
+                v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                ts.nodes++; ts.lane_nodes++;
+                float tn0, tn1;
+                bool h0, h1;
+                box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
+                int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+                if (h0 && h1) {
+                    const bool swap = tn1 < tn0;      // nearer box first: an occluder, if any, tends to be met sooner
+                    if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
+                    cur = swap ? c1 : c0;
+                } else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp > 0) cur = stack[--sp];
+                else verdict = 0;
+            } else {
+                const float4* lf = S.leaf + 3 * (size_t)(~cur);
+                float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
+                if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
+                ts.lane_prims++;
+                float d2 = 0;
+                HitUV cand;
+                if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand)) verdict = 1;
+                else if (sp > 0) cur = stack[--sp];
+                else verdict = 0;
+            }
+            if (verdict >= 0) {
+                P.occl[first + k] = (uint8_t)verdict;
+                alive = false;
+            }
+        }
+        const unsigned long long idle = ~ballot64(alive);
+        if (next < count && __popcll(idle) >= REFILL_MIN) {
+            if (!alive) {
+                uint32_t rel = next + (uint32_t)__popcll(idle & below);
+                if (rel < count) { k = rel; start(k); alive = true; }
+            }
+            next += (uint32_t)__popcll(idle);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- shadow (any hit)
 // The shadow query of getColor (src/raytrace.cpp:523-539) for every
 // (hit, light) pair of the generation: one work item per pair.
@@ -778,6 +1003,17 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
     if (ACCEL == 1) {
         for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items; base += (uint64_t)gridDim.x * blockDim.x)
             one(base + threadIdx.x);
+    } else if (ACCEL == 2) {
+        // chunks of several 64-item groups when there is enough work for every wave to get a few
+        const uint64_t groups = (items + 63) >> 6;
+        const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+        uint64_t per = groups / (waves * 4);
+        per = per < 1 ? 1 : (per > REFILL_GROUPS ? REFILL_GROUPS : per);
+        const uint64_t span = per << 6;
+        for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + span - 1) / span, [&](uint64_t c) {
+            const uint64_t first = c * span;
+            shadow_chunk(S, P, first, first + span < items ? first + span : items, ts);
+        });
     } else {
         for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + 63) >> 6,
                        [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });

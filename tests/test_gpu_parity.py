@@ -223,6 +223,32 @@ def test_both_hierarchies_render_the_same_image(tracer, monkeypatch):
     assert st_k.rays == st_p.rays
 
 
+@pytest.mark.parametrize("name,kw", [("dragon", dict(width=256, height=160, spp=4)),
+                                     ("plant_h_smooth", dict(width=165, height=128, spp=1, max_depth=8)),
+                                     ("outdoor_spot", dict(width=200, height=120, spp=2))])
+def test_every_walk_renders_the_same_image(tracer, monkeypatch, name, kw):
+    """Per-lane walks everywhere, packet walks everywhere, brute force: one image, bit for bit."""
+    scene = load_scene(name).copy(**kw)
+    tracer.load_scene(scene)
+    rgb0, f0, st0 = tracer.render(want_float=True)
+    images = {}
+    for label, n in (("lane", "0"), ("packet", "99")):
+        monkeypatch.setenv("RT_PACKET_GENS", n)
+        monkeypatch.setenv("RT_PACKET_SHADOW_GENS", n)
+        with ra.Tracer(device=0, accel=ra.RT_ACCEL_LBVH) as t:
+            t.load_scene(scene)
+            images[label] = t.render(want_float=True)
+    monkeypatch.delenv("RT_PACKET_GENS")
+    monkeypatch.delenv("RT_PACKET_SHADOW_GENS")
+    with ra.Tracer(device=0, accel=ra.RT_ACCEL_BRUTE) as t:
+        t.load_scene(scene)
+        images["brute"] = t.render(want_float=True)
+    for label, (rgb, f, st) in images.items():
+        assert np.array_equal(rgb, rgb0), label
+        assert np.array_equal(bits(f), bits(f0)), label
+        assert st.rays == st0.rays, label
+
+
 def test_edge_cases(tracer):
     # empty scene: background everywhere, no secondary or shadow rays
     s = ra.SceneArrays(width=70, height=33, background=np.array([.25, .5, 1], np.float32))
