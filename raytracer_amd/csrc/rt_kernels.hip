@@ -641,6 +641,9 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc&
 #ifndef REFILL_MIN
 #define REFILL_MIN 16
 #endif
+#ifndef LEAF_MIN
+#define LEAF_MIN 12
+#endif
 #define LANE_DONE ((int)0x80000000)   // ~(2^31 - 1): never a leaf slot
 
 
@@ -680,24 +683,29 @@ __device__ inline void extend_chunk(const DScene& S, const DPool& P, const GenSr
     if (k < n) begin(k);
     while (true) {
         if (ballot64(state != IDLE) == 0ull) break;
-        if (state == WALK) {
-            if (cur >= 0) {
-                const v4f* nd = nodes + 4 * (size_t)cur;
-                v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-                ts.nodes++; ts.lane_nodes++;
-                float tn0, tn1;
-                bool h0, h1;
-                box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
-                int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
-                if (h0 && h1) {
-                    const bool swap = tn1 < tn0;
-                    if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
-                    cur = swap ? c1 : c0;
-                } else if (h0) cur = c0;
-                else if (h1) cur = c1;
-                else if (sp > 0) cur = stack[--sp];
-                else state = FIN;
-            } else {
+        const bool at_node = state == WALK && cur >= 0;
+        if (at_node) {
+            const v4f* nd = nodes + 4 * (size_t)cur;
+            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            ts.nodes++; ts.lane_nodes++;
+            float tn0, tn1;
+            bool h0, h1;
+            box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
+            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp > 0) cur = stack[--sp];
+            else state = FIN;
+        }
+        // lanes at a leaf wait until LEAF_MIN of them are (see shadow_chunk)
+        const bool at_leaf = state == WALK && !at_node;
+        const unsigned long long leafm = ballot64(at_leaf);
+        if (leafm != 0ull && (__popcll(leafm) >= LEAF_MIN || ballot64(at_node) == 0ull)) {
+            if (at_leaf) {
                 const float4* lf = S.leaf + 3 * (size_t)(~cur);
                 float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
                 int prim = (int)fbits(l2.y);
@@ -934,25 +942,32 @@ __device__ inline void shadow_chunk(const DScene& S, const DPool& P, uint64_t fi
     };
     if (alive) start(k);
     while (ballot64(alive) != 0ull) {
-        if (alive) {
-            int verdict = -1;            // 0: reaches the light, 1: occluded
-            if (cur >= 0) {
-                const v4f* nd = nodes + 4 * (size_t)cur;
-                v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-                ts.nodes++; ts.lane_nodes++;
-                float tn0, tn1;
-                bool h0, h1;
-                box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
-                int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
-                if (h0 && h1) {
-                    const bool swap = tn1 < tn0;      // nearer box first: an occluder, if any, tends to be met sooner
-                    if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
-                    cur = swap ? c1 : c0;
-                } else if (h0) cur = c0;
-                else if (h1) cur = c1;
-                else if (sp > 0) cur = stack[--sp];
-                else verdict = 0;
-            } else {
+        int verdict = -1;                // 0: reaches the light, 1: occluded
+        const bool at_node = alive && cur >= 0;
+        if (at_node) {
+            const v4f* nd = nodes + 4 * (size_t)cur;
+            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            ts.nodes++; ts.lane_nodes++;
+            float tn0, tn1;
+            bool h0, h1;
+            box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
+            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;      // nearer box first: an occluder, if any, tends to be met sooner
+                if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp > 0) cur = stack[--sp];
+            else verdict = 0;
+        }
+        // The exact primitive test is four times the cost of a node step and only a few lanes
+        // want it at any time: lanes that have reached a leaf wait until LEAF_MIN have (or
+        // nobody is descending any more), then test together.
+        const bool at_leaf = alive && !at_node;
+        const unsigned long long leafm = ballot64(at_leaf);
+        if (leafm != 0ull && (__popcll(leafm) >= LEAF_MIN || ballot64(at_node) == 0ull)) {
+            if (at_leaf) {
                 const float4* lf = S.leaf + 3 * (size_t)(~cur);
                 float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
                 if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
@@ -963,10 +978,10 @@ __device__ inline void shadow_chunk(const DScene& S, const DPool& P, uint64_t fi
                 else if (sp > 0) cur = stack[--sp];
                 else verdict = 0;
             }
-            if (verdict >= 0) {
-                P.occl[first + k] = (uint8_t)verdict;
-                alive = false;
-            }
+        }
+        if (verdict >= 0) {
+            P.occl[first + k] = (uint8_t)verdict;
+            alive = false;
         }
         const unsigned long long idle = ~ballot64(alive);
         if (next < count && __popcll(idle) >= REFILL_MIN) {
@@ -1010,10 +1025,15 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
         uint64_t per = groups / (waves * 4);
         per = per < 1 ? 1 : (per > REFILL_GROUPS ? REFILL_GROUPS : per);
         const uint64_t span = per << 6;
-        for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + span - 1) / span, [&](uint64_t c) {
-            const uint64_t first = c * span;
-            shadow_chunk(S, P, first, first + span < items ? first + span : items, ts);
-        });
+        if (per == 1) {      // too little work to refill from: plain 64-item groups
+            for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, groups,
+                           [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });
+        } else {
+            for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + span - 1) / span, [&](uint64_t c) {
+                const uint64_t first = c * span;
+                shadow_chunk(S, P, first, first + span < items ? first + span : items, ts);
+            });
+        }
     } else {
         for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + 63) >> 6,
                        [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });
