@@ -20,6 +20,11 @@
 #include "rt_kernels.h"
 #include "rt_packet_asm.h"
 
+// k_shade: the compiler settles for 3 waves per SIMD (150 VGPRs) although 128 registers cost it nothing;
+// the kernel is latency-bound, so the fourth wave is free speed.
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
 #ifdef RT_WAVES
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES)))
 #else
@@ -1047,7 +1052,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
 // generation are written at the offsets the scan assigned (or, past max_depth,
 // the background is added directly as evaluateRayTree :132-135 returns it
 // without tracing).
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, DPool P, DCounters* C, int g) {
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES))) void k_shade(DScene S, DPool P, DCounters* C, int g) {
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
