@@ -28,7 +28,11 @@
 #ifdef RT_WAVES
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES)))
 #else
-#define RT_WAVES_ATTR
+// the per-lane walks hide memory latency with waves: 5 per SIMD at the price of a few spilled dwords
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ACCEL == 2 ? RT_LANE_WAVES : 1, 8)))
+#endif
+#ifndef RT_LANE_WAVES
+#define RT_LANE_WAVES 5
 #endif
 
 #include <algorithm>
