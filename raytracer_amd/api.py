@@ -109,6 +109,7 @@ def load_library():
         "rt_free_scene": (None, [C.POINTER(RtSceneDesc)]),
         "rt_output_name": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
         "rt_write_bmp24": (C.c_int, [C.c_char_p, vp, C.c_int, C.c_int]),
+        "rt_set_work_counters": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared entry point
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_strerror", "rt_last_error", "rt_load_scene", "rt_render",
     "rt_render_device", "rt_shard_tiles", "rt_shard_bytes", "rt_render_shard", "rt_assemble_shards",
     "rt_query_rays", "rt_primary_rays", "rt_jitter_hash", "rt_parse_scene_file", "rt_free_scene",
-    "rt_output_name", "rt_write_bmp24",
+    "rt_output_name", "rt_write_bmp24", "rt_set_work_counters",
 ]
 
 
@@ -360,6 +361,12 @@ class Tracer:
         rc = self._lib.rt_assemble_shards(self._ctx, d_all, world, d_rgb)
         if rc != RT_OK:
             raise RtError(rc, "rt_assemble_shards")
+
+    def set_work_counters(self, on: bool):
+        """Count node / primitive fetches and tests into RtStats from the next render on (slower)."""
+        rc = self._lib.rt_set_work_counters(self._ctx, 1 if on else 0)
+        if rc != RT_OK:
+            raise RtError(rc, "rt_set_work_counters")
 
     def query_rays(self, o, d, dmax=None, any_hit: bool = False, accel: int = RT_ACCEL_BRUTE):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)

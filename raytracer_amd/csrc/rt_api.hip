@@ -63,6 +63,7 @@ struct rt_ctx {
     // incoherent ones the per-lane walk); RT_PACKET_GENS / RT_PACKET_SHADOW_GENS force it.
     int8_t mode_extend[RT_MAX_GEN + 1], mode_shadow[RT_MAX_GEN + 1];
     bool tuned = false, forced_modes = false;
+    bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
     DScene S{};
     DCamera cam{};
     float4* d_sph = nullptr; int* d_sph_mat = nullptr;
@@ -99,7 +100,7 @@ static void free_scene(rt_ctx* c) {
 }
 static void free_pool(rt_ctx* c) {
     hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.hd); hipFree(c->P.loc);
-    hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.occl); hipFree(c->P.scol);
+    hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.link); hipFree(c->P.wstats); hipFree(c->P.occl); hipFree(c->P.scol);
     hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr); hipFree(c->P.hit_base);
     hipFree(c->P.child_base); hipFree(c->P.blocksum); hipFree(c->P.hitlist); hipFree(c->P.wq);
     c->P = DPool{};
@@ -118,6 +119,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     rt_ctx* c = new rt_ctx();
     if (opt) c->opt = *opt;
     for (int g = 0; g <= RT_MAX_GEN; g++) { c->mode_extend[g] = 3; c->mode_shadow[g] = 3; }
+    if (const char* e = getenv("RT_COUNT_WORK")) c->count_work = atoi(e) != 0;
     if (const char* e = getenv("RT_PACKET_GENS")) {
         c->forced_modes = true;
         for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_extend[g] = g < atoi(e) ? 3 : 2;
@@ -339,7 +341,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_pool(c);
-    if (capacity > 0xFFFFFFF0ull) { rt_set_error("ray pool beyond 2^32 records"); return RT_ERR_INVALID; }
+    if (capacity > 0x7FFFFFF0ull) { rt_set_error("ray pool beyond 2^31 records"); return RT_ERR_INVALID; }
     HIP_TRY(hipMalloc(&c->P.o, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.d, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.hp, capacity * sizeof(float4)));
@@ -348,7 +350,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.loc, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.cre, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.cra, capacity * sizeof(float4)));
-    uint64_t groups = capacity / 64 + 2, sblocks = groups / 256 + 2;
+    uint64_t groups = capacity / 64 + RT_MAX_GEN + 4, sblocks = groups / 256 + 2;
     HIP_TRY(hipMalloc(&c->P.mask_hit, groups * 8));
     HIP_TRY(hipMalloc(&c->P.mask_refl, groups * 8));
     HIP_TRY(hipMalloc(&c->P.mask_refr, groups * 8));
@@ -359,6 +361,8 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.occl, occl));
     HIP_TRY(hipMalloc(&c->P.scol, samples * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.wq, (size_t)2 * (RT_MAX_GEN + 1) * RT_WQ_LAUNCH * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->P.link, capacity * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->P.wstats, (size_t)2 * RT_MAX_WAVES * 8 * sizeof(unsigned long long)));
     c->P.capacity = (uint32_t)capacity;
     c->pool_capacity = capacity; c->scol_capacity = samples; c->occl_capacity = occl;
     return RT_OK;
@@ -412,11 +416,11 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
         if (c->accel == RT_ACCEL_LBVH) { acc_e = c->mode_extend[g]; acc_s = c->mode_shadow[g]; }
-        rtk_extend(st, acc_e, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks);
+        rtk_extend(st, acc_e, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work);
         tm.mark(0);
         rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
         tm.mark(3);
-        rtk_shadow(st, acc_s, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
+        rtk_shadow(st, acc_s, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, c->count_work);
         tm.mark(1);
         rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
         tm.mark(2);
@@ -425,6 +429,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     for (int g = S.max_depth - 1; g >= 0; g--)
         rtk_resolve(st, S, c->P, c->d_counters, g, std::min<uint64_t>((uint64_t)nsamples << std::min(g, 20), cap), c->max_blocks);
     rtk_finish(st, c->cam, c->P, c->d_tiles, tile0, npixels, shard_mode, d_out, d_outf, c->max_blocks);
+    if (c->count_work) rtk_reduce_stats(st, c->P, c->d_counters);
     tm.mark(3);
     DCounters hc;
     HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
@@ -511,11 +516,11 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                 uint64_t bound = nsamples;
                 for (int g = 0; g < G; g++) {
                     hipEventRecord(ev[4 * g + 0], st);
-                    rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks);
+                    rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false);
                     hipEventRecord(ev[4 * g + 1], st);
                     rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
                     hipEventRecord(ev[4 * g + 2], st);
-                    rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks);
+                    rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false);
                     hipEventRecord(ev[4 * g + 3], st);
                     rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
                     bound = std::min<uint64_t>(bound * 2, c->P.capacity);
@@ -761,6 +766,12 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
 #undef Q_TRY
     cleanup();
     return rc;
+}
+
+extern "C" int rt_set_work_counters(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_INVALID;
+    c->count_work = on != 0;
+    return RT_OK;
 }
 
 extern "C" int rt_primary_rays(rt_ctx* c, int64_t n, const int32_t* x, const int32_t* y, const int32_t* j,

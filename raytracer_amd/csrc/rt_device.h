@@ -94,6 +94,7 @@ struct DScene {
 // Work distribution of the traversal kernels: RT_NQ counters per launch, each on a cache
 // line of its own (a line sustains only ~90 returning atomics per microsecond), queue q
 // handing out the 64-ray groups q, q + RT_NQ, q + 2 RT_NQ, ...
+#define RT_MAX_WAVES 8192                                 // wave slots of the statistics array (>= waves of the largest traversal grid)
 #define RT_NQ 256
 #define RT_WQ_STRIDE 32                                  // uint32 per counter = 128 bytes
 #define RT_WQ_LAUNCH (RT_NQ * RT_WQ_STRIDE)              // uint32 per launch
@@ -104,18 +105,21 @@ struct DPool {
     uint32_t* wq;     // work-queue counters: launch slot 2g (extend of generation g), 2g+1 (shadow); zeroed per batch
     float4* o;        // origin xyz, w = parent code (bits): gen 0 -> sample index; else parent ray index
     float4* d;        // direction xyz, w = child slot (0 reflection, 1 refraction)
-    float4* loc;      // local colour rgb, w = pending code (bits): 0 = delivered,
-                      //   else (mat << 2 | refl | refr<<1) + 4  (children still to be added)
+    float4* loc;      // rays that spawned children only: local colour rgb, w = (mat << 2 | refl | refr<<1) (bits)
     float4* cre;      // colour returned by the reflection child
     float4* cra;      // colour returned by the refraction child
+    unsigned long long* wstats;   // [2][RT_MAX_WAVES][8] traversal work counters per wave slot (closest-hit, any-hit), see flush_stats
+    uint32_t* link;   // generations >= 1: parent ray | child slot << 31, written with the ray (dense, in ray order)
     // per ray of the CURRENT generation (index = ray - generation start), rewritten every generation
     float4* hp;       // hit point xyz, w = primitive id (bits)           [hit rays only]
     float4* hn;       // shading normal xyz, w = material id | child slot << 31 (bits)
     float4* hd;       // direction of the ray that hit, w = parent code (as in o.w)
-    // per 64-ray group of the current generation: wave ballots and their prefix sums
+    // per 64-ray group: wave ballots, kept for every generation of the batch (index gbase[g] + group:
+    // the bottom-up resolve pass finds the rays with pending children in them) ...
     unsigned long long* mask_hit;    // ray hit something
     unsigned long long* mask_refl;   // hit spawns a reflection ray
     unsigned long long* mask_refr;   // hit spawns a refraction ray
+    // ... and their prefix sums, for the current generation only (index = group)
     uint32_t* hit_base;    // hits before the group
     uint32_t* child_base;  // next-generation rays before the group
     uint2* blocksum;       // scan scratch: per 256 groups (hits, children)
@@ -127,6 +131,7 @@ struct DPool {
 
 struct DCounters {
     uint32_t gen_count[RT_MAX_GEN + 1];   // rays per generation (appended by the shade kernel of g-1)
+    uint32_t gbase[RT_MAX_GEN + 2];       // first 64-ray group of each generation in the mask arrays (groups never straddle generations)
     uint32_t hit_count[RT_MAX_GEN + 1];   // hits per generation
     uint32_t overflow;                    // set when a spawn did not fit the pool
     uint32_t pad;

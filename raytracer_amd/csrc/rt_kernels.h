@@ -8,11 +8,12 @@
 void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations);
 // generation 0 is generated on the fly from (cam, tiles, tile0); deeper generations read the pool
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
-                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks);
+                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count);
 // prefix sums over the wave masks of generation g: hit list, hit / next-generation counts, child offsets
+void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C);
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
-                uint64_t bound, int max_blocks);
+                uint64_t bound, int max_blocks, bool count);
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks);

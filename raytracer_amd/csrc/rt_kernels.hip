@@ -38,12 +38,12 @@
 #include <algorithm>
 
 // ---------------------------------------------------------------- small helpers
-__device__ inline uint32_t gen_start(const DCounters* __restrict__ c, int g) {
+__device__ __forceinline__ uint32_t gen_start(const DCounters* __restrict__ c, int g) {
     uint32_t s = 0;
     for (int i = 0; i < g; i++) s += c->gen_count[i];
     return s;
 }
-__device__ inline uint32_t gen_size(const DCounters* __restrict__ c, int g, uint32_t start,
+__device__ __forceinline__ uint32_t gen_size(const DCounters* __restrict__ c, int g, uint32_t start,
                                     uint32_t capacity) {
     uint32_t n = c->gen_count[g];
     if (start >= capacity) return 0;
@@ -58,13 +58,13 @@ __device__ inline uint32_t gen_size(const DCounters* __restrict__ c, int g, uint
 // (issued BEFORE the current group is processed, so its latency is hidden), and once
 // the home queue is empty it helps RT_WQ_PROBES neighbours.  The group a wave processes
 // only selects WHICH rays it works on; results land at positions fixed by the ray index.
-__device__ inline uint32_t wq_grab(uint32_t* counter, uint32_t lane) {
+__device__ __forceinline__ uint32_t wq_grab(uint32_t* counter, uint32_t lane) {
     uint32_t k = 0;
     if (lane == 0) k = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return k;
 }
 template <class F>
-__device__ inline void for_each_group(uint32_t* wq, uint64_t ngroups, F&& body) {
+__device__ __forceinline__ void for_each_group(uint32_t* wq, uint64_t ngroups, F&& body) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t q = wave % RT_NQ;
@@ -84,7 +84,7 @@ __device__ inline void for_each_group(uint32_t* wq, uint64_t ngroups, F&& body) 
     }
 }
 
-__device__ inline void deliver(const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c) {
+__device__ __forceinline__ void deliver(const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c) {
     float4 v = make_float4(c.x, c.y, c.z, 0.0f);
     if (g == 0) P.scol[parent] = v;
     else if (slot == 0) P.cre[parent] = v;
@@ -107,7 +107,7 @@ struct TraceStats {
 };
 
 template <bool ANY>
-__device__ inline void brute_trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
+__device__ __forceinline__ void brute_trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
                                    int& best, float& best_d2, HitUV& uv, TraceStats& ts) {
     double dd = (double)dot3(d, d);
     best = -1;
@@ -173,7 +173,7 @@ struct SlabRay {
     F3 inv, noi;   // 1 / d and -(o / d)
     float inv_dd;  // 1 / dot(d, d)
 };
-__device__ inline SlabRay slab_ray(F3 o, F3 d) {
+__device__ __forceinline__ SlabRay slab_ray(F3 o, F3 d) {
     F3 ds = f3(__builtin_fabsf(d.x) < 1e-20f ? __builtin_copysignf(1e-20f, d.x) : d.x,
                __builtin_fabsf(d.y) < 1e-20f ? __builtin_copysignf(1e-20f, d.y) : d.y,
                __builtin_fabsf(d.z) < 1e-20f ? __builtin_copysignf(1e-20f, d.z) : d.z);
@@ -188,7 +188,7 @@ __device__ inline SlabRay slab_ray(F3 o, F3 d) {
 // by 1e-4 -- three orders of magnitude above the error of the approximate reciprocal and
 // square root -- so it only ever culls boxes that lie wholly beyond the bound.  An
 // infinite (or NaN) bound culls nothing.
-__device__ inline float slab_tmax(const SlabRay& r, float d2) {
+__device__ __forceinline__ float slab_tmax(const SlabRay& r, float d2) {
     return __builtin_amdgcn_sqrtf(d2 * r.inv_dd) * 1.0001f;
 }
 
@@ -196,7 +196,7 @@ __device__ inline float slab_tmax(const SlabRay& r, float d2) {
 // the direction are known (bit k set = negative along axis k), so near and far planes
 // are picked at compile time; OCT == 8: any direction, min / max per axis.
 template <int OCT>
-__device__ inline bool slab_hit(v2f x, v2f y, v2f z, float tmax, float& tnear) {
+__device__ __forceinline__ bool slab_hit(v2f x, v2f y, v2f z, float tmax, float& tnear) {
     float nx, fx, ny, fy, nz, fz;
     if (OCT == 8) {
         nx = fminf(x.x, x.y); fx = fmaxf(x.x, x.y);
@@ -213,7 +213,7 @@ __device__ inline bool slab_hit(v2f x, v2f y, v2f z, float tmax, float& tnear) {
     return tn <= fminf(tf * 1.0000005f, tmax);
 }
 template <int OCT>
-__device__ inline void box_pair(v4f q0, v4f q1, v4f q2, const SlabRay& R, float tmax, bool& h0, bool& h1,
+__device__ __forceinline__ void box_pair(v4f q0, v4f q1, v4f q2, const SlabRay& R, float tmax, bool& h0, bool& h1,
                                 float& tn0, float& tn1) {
     const v2f ix = {R.inv.x, R.inv.x}, iy = {R.inv.y, R.inv.y}, iz = {R.inv.z, R.inv.z};
     const v2f ox = {R.noi.x, R.noi.x}, oy = {R.noi.y, R.noi.y}, oz = {R.noi.z, R.noi.z};
@@ -228,7 +228,7 @@ __device__ inline void box_pair(v4f q0, v4f q1, v4f q2, const SlabRay& R, float 
 }
 
 // exact test of one tree-ordered leaf record (see rt_lbvh.hip: k_leaves)
-__device__ inline bool leaf_test(F3 o, F3 d, double dd, float4 l0, float4 l1, float4 l2, float dmax,
+__device__ __forceinline__ bool leaf_test(F3 o, F3 d, double dd, float4 l0, float4 l1, float4 l2, float dmax,
                                  float& d2, HitUV& uv) {
     if (fbits(l2.z) != 0u) return sphere_test(o, d, dd, l0, dmax, d2, uv.a);
     TriHit h;
@@ -240,7 +240,7 @@ __device__ inline bool leaf_test(F3 o, F3 d, double dd, float4 l0, float4 l1, fl
 
 // Per-lane while-while traversal with a private stack: every lane walks its own path.
 template <bool ANY>
-__device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
+__device__ __forceinline__ void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
                                   float& best_d2, HitUV& uv, TraceStats& ts) {
     best = -1;
     best_d2 = dmax;
@@ -303,10 +303,10 @@ __device__ inline void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, floa
 // When all rays of the wave point into the same octant -- primary rays, shadow
 // rays of a directional light -- the descent runs a variant compiled for that
 // octant, which needs no per-axis min / max.  All 64 lanes must call.
-__device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // one entry of the wave-shared stack: lane `sel` of v takes the wave-uniform value
-__device__ inline void lane_write(int& v, int value, int sel) {
+__device__ __forceinline__ void lane_write(int& v, int value, int sel) {
     // the lane select goes through m0 (saved and restored): gfx9 VALU encodings may name
     // only one SGPR besides it
     int keep;
@@ -328,7 +328,7 @@ struct PacketState {
 // Walks inner nodes from `cur` until a leaf comes up (returned, < 0) or the stack is
 // empty (PACKET_DONE).
 template <int OCT>
-__device__ inline int packet_descend(cv4p nodes, int cur, const SlabRay& R, float tmax, PacketState& st) {
+__device__ __forceinline__ int packet_descend(cv4p nodes, int cur, const SlabRay& R, float tmax, PacketState& st) {
     while (cur >= 0) {
         cv4p nd = nodes + 4 * (size_t)cur;
         v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
@@ -362,7 +362,7 @@ __device__ inline int packet_descend(cv4p nodes, int cur, const SlabRay& R, floa
 }
 
 template <bool ANY, bool FAST>
-__device__ inline void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
+__device__ __forceinline__ void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
                                               float& best_d2, HitUV& uv, TraceStats& ts) {
     best = -1;
     best_d2 = dmax;
@@ -452,14 +452,14 @@ __device__ inline void lbvh_trace_packet_impl(const DScene& S, bool active, F3 o
 // Trees at most 64 deep (all but degenerate scenes) take the hand-scheduled descent, whose
 // stack is one register wide; deeper ones the compiled one.
 template <bool ANY>
-__device__ inline void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
+__device__ __forceinline__ void lbvh_trace_packet(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
                                          float& best_d2, HitUV& uv, TraceStats& ts) {
     if (S.depth <= 64) lbvh_trace_packet_impl<ANY, true>(S, active, o, d, dmax, best, best_d2, uv, ts);
     else lbvh_trace_packet_impl<ANY, false>(S, active, o, d, dmax, best, best_d2, uv, ts);
 }
 
 template <int ACCEL, bool ANY>
-__device__ inline void trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
+__device__ __forceinline__ void trace(const DScene& S, float4* lds, bool active, F3 o, F3 d, float dmax,
                              int& best, float& best_d2, HitUV& uv, TraceStats& ts) {
     uv.a = 0; uv.b = 0;
     if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, uv, ts);
@@ -467,27 +467,52 @@ __device__ inline void trace(const DScene& S, float4* lds, bool active, F3 o, F3
     else lbvh_trace_packet<ANY>(S, active, o, d, dmax, best, best_d2, uv, ts);
 }
 
-__device__ inline void flush_stats(DCounters* C, int which, const TraceStats& ts) {
+// Work counters of a traversal launch.  Every wave adds its totals to a slot of its own
+// (plain loads and stores: the slot belongs to this wave id for the launch, and launches
+// of a batch follow one another), and one small kernel sums the slots at the end of the
+// batch.  Adding them to shared counters with atomics instead costs a fifth of the frame:
+// thousands of waves finish together and their atomics queue up on one cache line.
+__device__ __forceinline__ void flush_stats(const DPool& P, DCounters* C, int which, const TraceStats& ts) {
     unsigned long long v[5] = {ts.nodes, ts.sph, ts.tri, ts.lane_nodes, ts.lane_prims};
     for (int k = 0; k < 5; k++)
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
     if ((threadIdx.x & 63) == 0) {
-        if (v[0]) atomicAdd(&C->nodes[which], v[0]);
-        if (v[1]) atomicAdd(&C->sph_tests[which], v[1]);
-        if (v[2]) atomicAdd(&C->tri_tests[which], v[2]);
-        if (v[3]) atomicAdd(&C->lane_nodes[which], v[3]);
-        if (v[4]) atomicAdd(&C->lane_prims[which], v[4]);
-        if (ts.walks) {
+        const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (wave < RT_MAX_WAVES) {
+            unsigned long long* slot = P.wstats + ((size_t)which * RT_MAX_WAVES + wave) * 8;
+            for (int k = 0; k < 5; k++)
+                if (v[k]) slot[k] += v[k];
+        }
+        if (ts.walks) {   // tuning aid (RT_PROFILE) only
             atomicAdd(&C->prof_walk_cycles[which], ts.walk_cycles); atomicAdd(&C->prof_steps[which], ts.steps);
             atomicAdd(&C->prof_walks[which], ts.walks);
         }
     }
 }
 
+__global__ void k_reduce_stats(DPool P, DCounters* C) {   // one block per counter: blockIdx.x = which * 5 + k
+    __shared__ unsigned long long red[256];
+    const int which = blockIdx.x / 5, k = blockIdx.x % 5;
+    unsigned long long sum = 0;
+    for (uint32_t w = threadIdx.x; w < RT_MAX_WAVES; w += blockDim.x)
+        sum += P.wstats[((size_t)which * RT_MAX_WAVES + w) * 8 + k];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long* dst = k == 0 ? C->nodes : k == 1 ? C->sph_tests : k == 2 ? C->tri_tests
+                                : k == 3 ? C->lane_nodes : C->lane_prims;
+        dst[which] = red[0];
+    }
+}
+
 // ---------------------------------------------------------------- generate
 // Pixel of local pixel index lp: tiles of RT_TILE_PX^2 pixels, 8x8 sub-blocks inside
 // a tile so that the 64 lanes of a wave cover a compact screen region.
-__device__ inline void pixel_of(const uint32_t* __restrict__ tiles, uint32_t tile0, uint32_t lp,
+__device__ __forceinline__ void pixel_of(const uint32_t* __restrict__ tiles, uint32_t tile0, uint32_t lp,
                                 int& x, int& y, int& px, int& py, uint32_t& tile) {
     tile = tile0 + (lp >> 10);
     uint32_t pin = lp & 1023u;
@@ -500,7 +525,7 @@ __device__ inline void pixel_of(const uint32_t* __restrict__ tiles, uint32_t til
 }
 
 // RayTrace::getRay (src/raytrace.cpp:441-485) for one sample.
-__device__ inline void primary_ray(const DCamera& cam, int x, int y, int j, F3& o, F3& d) {
+__device__ __forceinline__ void primary_ray(const DCamera& cam, int x, int y, int j, F3& o, F3& d) {
     double r1, r2;
     if (cam.spp > 1) {
         unsigned long long c = (((unsigned long long)y * (unsigned long long)cam.width +
@@ -533,7 +558,7 @@ struct GenSrc {        // what generation 0 is generated from
     const uint32_t* tiles;
     uint32_t tile0;
 };
-__device__ inline RayRec load_ray(const DPool& P, const GenSrc& G, int g, uint32_t i, uint32_t r) {
+__device__ __forceinline__ RayRec load_ray(const DPool& P, const GenSrc& G, int g, uint32_t i, uint32_t r) {
     RayRec R;
     if (g == 0) {
         uint32_t lp = i / (uint32_t)G.cam.spp;
@@ -565,7 +590,7 @@ __global__ void k_primary_rays(DCamera cam, int64_t n, const int* x, const int* 
 
 __global__ void k_init_counters(DCounters* C, uint32_t nsamples) {
     int i = threadIdx.x;
-    if (i <= RT_MAX_GEN) { C->gen_count[i] = (i == 0) ? nsamples : 0; C->hit_count[i] = 0; }
+    if (i <= RT_MAX_GEN) { C->gen_count[i] = (i == 0) ? nsamples : 0; C->hit_count[i] = 0; C->gbase[i] = 0; }
     if (i == 0) { C->overflow = 0; C->pad = 0; }
     if (i < 2) {
         C->nodes[i] = 0; C->sph_tests[i] = 0; C->tri_tests[i] = 0; C->lane_nodes[i] = 0; C->lane_prims[i] = 0;
@@ -583,7 +608,7 @@ struct Spawn {
     bool refl, refr;
     double dni, ior, tir;
 };
-__device__ inline Spawn spawn_of(F3 spec, F3 trans, float iorf, F3 direct, F3 normal) {
+__device__ __forceinline__ Spawn spawn_of(F3 spec, F3 trans, float iorf, F3 direct, F3 normal) {
     Spawn s;
     s.refl = (spec.x != 0 && spec.y != 0 && spec.z != 0);
     s.refr = false;
@@ -611,8 +636,8 @@ __device__ inline Spawn spawn_of(F3 spec, F3 trans, float iorf, F3 direct, F3 no
 // preserves the coherence of neighbouring rays.
 // Every lane of the wave must call (ballots inside).
 template <int ACCEL>
-__device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
-                                  uint32_t count, uint32_t i, float4* lds, TraceStats& ts) {
+__device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
+                                  uint32_t count, uint32_t gbase, uint32_t i, float4* lds, TraceStats& ts) {
     bool inrange = i < count;
     uint32_t r = start + (inrange ? i : 0);
     RayRec R = load_ray(P, G, g, inrange ? i : 0, r);
@@ -635,11 +660,13 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc&
         }
     } else if (inrange) {
         if (active) deliver(P, g, R.parent, R.slot, S.bg);
-        P.loc[r] = make_float4(0, 0, 0, 0);   // nothing pending for the resolve pass
+#ifdef EXP_LOC
+        P.loc[r] = make_float4(0, 0, 0, 0);
+#endif
     }
     unsigned long long mh = __ballot(hit), m1 = __ballot(refl), m2 = __ballot(refr);
     if ((threadIdx.x & 63) == 0 && inrange) {
-        uint32_t grp = i >> 6;
+        uint32_t grp = gbase + (i >> 6);
         P.mask_hit[grp] = mh; P.mask_refl[grp] = m1; P.mask_refr[grp] = m2;
     }
 }
@@ -662,8 +689,8 @@ __device__ inline void extend_one(const DScene& S, const DPool& P, const GenSrc&
 // write their hit (or miss) records together and take the next rays of the chunk.  Rays
 // are finished out of order, so the three ballot masks of each 64-ray group are put
 // together at the end from one flag byte per ray kept in LDS (`flags`, this wave's own).
-__device__ inline void extend_chunk(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
-                                    uint32_t first, uint32_t n, uint8_t* flags, TraceStats& ts) {
+__device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
+                                    uint32_t gbase, uint32_t first, uint32_t n, uint8_t* flags, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const v4f* nodes = (const v4f*)S.nodes;
@@ -735,7 +762,7 @@ __device__ inline void extend_chunk(const DScene& S, const DPool& P, const GenSr
         const unsigned long long fin = ballot64(state == FIN);
         if (__popcll(fin) >= REFILL_MIN || ballot64(state == WALK) == 0ull) {
             if (state == FIN) {
-                const uint32_t i = first + k, r = start + i;
+                const uint32_t i = first + k;
                 uint32_t bits = 0;
                 if (valid && best >= 0) {
                     F3 point, normal; int mat;
@@ -751,7 +778,6 @@ __device__ inline void extend_chunk(const DScene& S, const DPool& P, const GenSr
                     }
                 } else {
                     if (valid) deliver(P, g, parent, slot, S.bg);
-                    P.loc[r] = make_float4(0, 0, 0, 0);
                 }
                 flags[k] = (uint8_t)bits;
                 state = IDLE;
@@ -771,24 +797,25 @@ __device__ inline void extend_chunk(const DScene& S, const DPool& P, const GenSr
         uint32_t f = (base + lane < n) ? flags[base + lane] : 0u;
         unsigned long long mh = ballot64(f & 1u), m1 = ballot64(f & 2u), m2 = ballot64(f & 4u);
         if (lane == 0) {
-            uint32_t grp = (first + base) >> 6;
+            uint32_t grp = gbase + ((first + base) >> 6);
             P.mask_hit[grp] = mh; P.mask_refl[grp] = m1; P.mask_refr[grp] = m2;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <int ACCEL>
+template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
     if (C->overflow) return;   // ray slots past an overflow were never written: the host re-runs the batch
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
+    const uint32_t gbase = C->gbase[g];
     TraceStats ts;
     unsigned long long tw = S.profile ? __builtin_readcyclecounter() : 0ull;
     if (ACCEL == 1) {   // block-wide LDS staging: the whole block moves together
         for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
-            extend_one<ACCEL>(S, P, G, g, start, count, base + threadIdx.x, lds, ts);
+            extend_one<ACCEL>(S, P, G, g, start, count, gbase, base + threadIdx.x, lds, ts);
     } else if (ACCEL == 2) {
         __shared__ uint8_t flags[RT_BLOCK / 64][REFILL_GROUPS * 64];
         const uint64_t groups = ((uint64_t)count + 63) >> 6;
@@ -798,21 +825,21 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
         const uint32_t span = (uint32_t)per << 6;
         if (per == 1) {      // too little work to refill from: plain 64-ray groups
             for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, groups, [&](uint64_t grp) {
-                extend_one<ACCEL>(S, P, G, g, start, count, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
+                extend_one<ACCEL>(S, P, G, g, start, count, gbase, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
             });
         } else {
             for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + span - 1) / span, [&](uint64_t c) {
                 const uint32_t first = (uint32_t)c * span;
-                extend_chunk(S, P, G, g, start, first, min(span, count - first), flags[threadIdx.x >> 6], ts);
+                extend_chunk(S, P, G, g, start, gbase, first, min(span, count - first), flags[threadIdx.x >> 6], ts);
             });
         }
     } else {
         for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + 63) >> 6, [&](uint64_t grp) {
-            extend_one<ACCEL>(S, P, G, g, start, count, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
+            extend_one<ACCEL>(S, P, G, g, start, count, gbase, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
         });
     }
     if (S.profile && (threadIdx.x & 63) == 0) atomicAdd(&C->prof_wave_cycles[0], __builtin_readcyclecounter() - tw);
-    flush_stats(C, 0, ts);
+    if (COUNT) flush_stats(P, C, 0, ts);   // never flushed = never counted: the compiler drops the counting above (profiling launches the counting variant)
 }
 
 // ---------------------------------------------------------------- queue compaction (prefix sums)
@@ -821,14 +848,14 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
 // generation totals; scan3: per-group bases + the compacted hit list.
 #define SCAN_BLOCK 256
 
-__device__ inline uint2 group_counts(const DPool& P, uint32_t grp, uint32_t ngroups) {
+__device__ __forceinline__ uint2 group_counts(const DPool& P, uint32_t gbase, uint32_t grp, uint32_t ngroups) {
     if (grp >= ngroups) return make_uint2(0, 0);
-    return make_uint2((uint32_t)__popcll(P.mask_hit[grp]),
-                      (uint32_t)(__popcll(P.mask_refl[grp]) + __popcll(P.mask_refr[grp])));
+    return make_uint2((uint32_t)__popcll(P.mask_hit[gbase + grp]),
+                      (uint32_t)(__popcll(P.mask_refl[gbase + grp]) + __popcll(P.mask_refr[gbase + grp])));
 }
 
 // block-wide exclusive scan of a uint2 (both components), returns the block total
-__device__ inline uint2 block_scan(uint2 v, uint2* lds /*[SCAN_BLOCK]*/, uint2& total) {
+__device__ __forceinline__ uint2 block_scan(uint2 v, uint2* lds /*[SCAN_BLOCK]*/, uint2& total) {
     const int t = threadIdx.x;
     lds[t] = v;
     __syncthreads();
@@ -853,7 +880,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(DPool P, DCounters* C, int
     const uint32_t ngroups = (count + 63) >> 6;
     const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        uint2 v = group_counts(P, b * SCAN_BLOCK + threadIdx.x, ngroups), total;
+        uint2 v = group_counts(P, C->gbase[g], b * SCAN_BLOCK + threadIdx.x, ngroups), total;
         block_scan(v, lds, total);
         if (threadIdx.x == 0) P.blocksum[b] = total;
     }
@@ -877,6 +904,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(DPool P, DCounters* C, int
     if (threadIdx.x == 0) {
         C->hit_count[g] = carry.x;
         C->gen_count[g + 1] = carry.y;
+        C->gbase[g + 1] = C->gbase[g] + ngroups;
         if ((uint64_t)start + C->gen_count[g] + carry.y > (uint64_t)P.capacity) C->overflow = 1;
     }
 }
@@ -892,7 +920,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int
     const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
         uint32_t grp = b * SCAN_BLOCK + threadIdx.x;
-        uint2 v = group_counts(P, grp, ngroups), total;
+        uint2 v = group_counts(P, C->gbase[g], grp, ngroups), total;
         uint2 ex = block_scan(v, lds, total);
         uint2 bs = P.blocksum[b];
         uint32_t hbase = bs.x + ex.x;
@@ -901,7 +929,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int
             P.child_base[grp] = bs.y + ex.y;
         }
         hb[threadIdx.x] = hbase;
-        hm[threadIdx.x] = (grp < ngroups) ? P.mask_hit[grp] : 0ull;
+        hm[threadIdx.x] = (grp < ngroups) ? P.mask_hit[C->gbase[g] + grp] : 0ull;
         __syncthreads();
         // compacted hit list of the block's 256 groups: one thread per ray, coalesced
         for (uint32_t k = threadIdx.x; k < SCAN_BLOCK * 64u; k += SCAN_BLOCK) {
@@ -922,7 +950,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int
 // idle lane takes the next item of the chunk (ballot + prefix count, no atomics), so the
 // wave stays full until the chunk runs out.  One loop iteration = one node or one leaf per
 // lane, exactly the step of lbvh_trace<true>.
-__device__ inline void shadow_chunk(const DScene& S, const DPool& P, uint64_t first, uint64_t end, TraceStats& ts) {
+__device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, uint64_t first, uint64_t end, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const v4f* nodes = (const v4f*)S.nodes;
@@ -1006,7 +1034,7 @@ __device__ inline void shadow_chunk(const DScene& S, const DPool& P, uint64_t fi
 // ---------------------------------------------------------------- shadow (any hit)
 // The shadow query of getColor (src/raytrace.cpp:523-539) for every
 // (hit, light) pair of the generation: one work item per pair.
-template <int ACCEL>
+template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPool P, DCounters* C, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
     if (C->overflow) return;
@@ -1047,7 +1075,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
         for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + 63) >> 6,
                        [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });
     }
-    flush_stats(C, 1, ts);
+    if (COUNT) flush_stats(P, C, 1, ts);
 }
 
 // ---------------------------------------------------------------- shade + spawn
@@ -1061,6 +1089,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
     const uint32_t next_start = start + C->gen_count[g];
+    const uint32_t gbase = C->gbase[g];
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x) {
         const uint32_t i = P.hitlist[h];
         const uint32_t r = start + i;
@@ -1119,21 +1148,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
         }
         if (leaf) {
             deliver(P, g, parent, slot, f3(rval, gval, bval));
-            P.loc[r] = make_float4(rval, gval, bval, 0.0f);
             continue;
         }
-        uint32_t code = 4u + (((uint32_t)mat << 2) | (sp.refl ? 1u : 0u) | (sp.refr ? 2u : 0u));
+        uint32_t code = ((uint32_t)mat << 2) | (sp.refl ? 1u : 0u) | (sp.refr ? 2u : 0u);
         P.loc[r] = make_float4(rval, gval, bval, bitsf(code));
         // where the scan put this ray's children: rays of the group before it first
         const uint32_t grp = i >> 6;
         const unsigned long long below = (1ull << (i & 63u)) - 1ull;
         uint64_t at = (uint64_t)next_start + P.child_base[grp] +
-                      (uint32_t)__popcll(P.mask_refl[grp] & below) + (uint32_t)__popcll(P.mask_refr[grp] & below);
+                      (uint32_t)__popcll(P.mask_refl[gbase + grp] & below) + (uint32_t)__popcll(P.mask_refr[gbase + grp] & below);
         if (at + (sp.refl ? 1u : 0u) + (sp.refr ? 1u : 0u) > (uint64_t)P.capacity) continue;   // overflow, flagged by the scan
         if (sp.refl) {
             F3 rfd = (normal * (2.0f * dot3(normal, irdir))) - irdir;
             P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
             P.d[at] = make_float4(rfd.x, rfd.y, rfd.z, bitsf(0u));
+            P.link[at] = r;
             at++;
         }
         if (sp.refr) {
@@ -1143,6 +1172,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
             F3 rad = norm3(refdir);
             P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
             P.d[at] = make_float4(rad.x, rad.y, rad.z, bitsf(1u));
+            P.link[at] = r | 0x80000000u;
         }
     }
 }
@@ -1155,12 +1185,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounte
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
+    const uint32_t gbase = C->gbase[g];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        // only rays that spawned children have anything pending: the spawn ballots say which
+        const uint32_t grp = gbase + (i >> 6);
+        const unsigned long long pending = P.mask_refl[grp] | P.mask_refr[grp];
+        if (!((pending >> (i & 63u)) & 1ull)) continue;
         uint32_t r = start + i;
         float4 l = P.loc[r];
         uint32_t code = fbits(l.w);
-        if (code < 4u) continue;
-        code -= 4u;
         const float4* M = S.mats + 4 * (size_t)(code >> 2);
         float rval = l.x, gval = l.y, bval = l.z;
         if (code & 1u) {
@@ -1172,7 +1205,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounte
             rval += t.x * c.x; gval += t.y * c.y; bval += t.z * c.z;
         }
         if (g == 0) deliver(P, 0, r, 0, f3(rval, gval, bval));
-        else deliver(P, g, fbits(P.o[r].w), fbits(P.d[r].w), f3(rval, gval, bval));
+        else {
+            const uint32_t link = P.link[r];
+            deliver(P, g, link & 0x7FFFFFFFu, link >> 31, f3(rval, gval, bval));
+        }
     }
 }
 
@@ -1180,7 +1216,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounte
 // ave (src/raytrace.cpp:1079-1089) then Pixel::SetClamp(c*255.0)
 // (src/raytrace.cpp:112, src/pixel.cpp:38-43): (int) truncation as x86-64
 // performs it (NaN and out-of-range become INT_MIN), then clamp to 0..255.
-__device__ inline uint8_t quantise(float c) {
+__device__ __forceinline__ uint8_t quantise(float c) {
     double v = (double)c * 255.0;
     int i;
     if (!(v == v) || v >= 2147483648.0 || v <= -2147483649.0) i = (-2147483647 - 1);
@@ -1284,6 +1320,7 @@ static inline int grid_for(uint64_t items, int max_blocks) {
 
 void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations) {
     hipMemsetAsync(P.wq, 0, (size_t)2 * generations * RT_WQ_LAUNCH * sizeof(uint32_t), st);
+    hipMemsetAsync(P.wstats, 0, (size_t)2 * RT_MAX_WAVES * 8 * sizeof(unsigned long long), st);
     hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(128), 0, st, C, nsamples);
 }
 // Traversal launches are persistent grids sized to what is RESIDENT at once: with
@@ -1298,17 +1335,23 @@ static int resident_blocks(K kernel, int max_blocks) {
     return std::min(max_blocks, std::max(1, per_cu) * cus);
 }
 
-void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
-                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks) {
-    GenSrc G{cam, tiles, tile0};
+template <bool COUNT>
+static void launch_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const GenSrc& G,
+                          int g, uint64_t bound, int max_blocks) {
     static int res[4] = {0, 0, 0, 0};
-    if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_extend<1>, max_blocks)
-                                 : accel == 2 ? resident_blocks(k_extend<2>, max_blocks)
-                                              : resident_blocks(k_extend<3>, max_blocks);
+    if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_extend<1, COUNT>, max_blocks)
+                                 : accel == 2 ? resident_blocks(k_extend<2, COUNT>, max_blocks)
+                                              : resident_blocks(k_extend<3, COUNT>, max_blocks);
     dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
-    if (accel == 1) hipLaunchKernelGGL(k_extend<1>, grid, block, 0, st, S, P, C, G, g);
-    else if (accel == 2) hipLaunchKernelGGL(k_extend<2>, grid, block, 0, st, S, P, C, G, g);
-    else hipLaunchKernelGGL(k_extend<3>, grid, block, 0, st, S, P, C, G, g);
+    if (accel == 1) hipLaunchKernelGGL((k_extend<1, COUNT>), grid, block, 0, st, S, P, C, G, g);
+    else if (accel == 2) hipLaunchKernelGGL((k_extend<2, COUNT>), grid, block, 0, st, S, P, C, G, g);
+    else hipLaunchKernelGGL((k_extend<3, COUNT>), grid, block, 0, st, S, P, C, G, g);
+}
+void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
+                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count) {
+    GenSrc G{cam, tiles, tile0};
+    if (count || S.profile) launch_extend<true>(st, accel, S, P, C, G, g, bound, max_blocks);
+    else launch_extend<false>(st, accel, S, P, C, G, g, bound, max_blocks);
 }
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {
     uint64_t groups = (bound + 63) / 64;
@@ -1318,21 +1361,30 @@ void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t b
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SCAN_BLOCK), 0, st, P, C, g);
     hipLaunchKernelGGL(k_scan3, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g);
 }
-void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
-                uint64_t bound, int max_blocks) {
-    if (S.nl == 0) return;
+template <bool COUNT>
+static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
+                          uint64_t bound, int max_blocks) {
     static int res[4] = {0, 0, 0, 0};
-    if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_shadow<1>, max_blocks)
-                                 : accel == 2 ? resident_blocks(k_shadow<2>, max_blocks)
-                                              : resident_blocks(k_shadow<3>, max_blocks);
+    if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_shadow<1, COUNT>, max_blocks)
+                                 : accel == 2 ? resident_blocks(k_shadow<2, COUNT>, max_blocks)
+                                              : resident_blocks(k_shadow<3, COUNT>, max_blocks);
     dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
-    if (accel == 1) hipLaunchKernelGGL(k_shadow<1>, grid, block, 0, st, S, P, C, g);
-    else if (accel == 2) hipLaunchKernelGGL(k_shadow<2>, grid, block, 0, st, S, P, C, g);
-    else hipLaunchKernelGGL(k_shadow<3>, grid, block, 0, st, S, P, C, g);
+    if (accel == 1) hipLaunchKernelGGL((k_shadow<1, COUNT>), grid, block, 0, st, S, P, C, g);
+    else if (accel == 2) hipLaunchKernelGGL((k_shadow<2, COUNT>), grid, block, 0, st, S, P, C, g);
+    else hipLaunchKernelGGL((k_shadow<3, COUNT>), grid, block, 0, st, S, P, C, g);
+}
+void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
+                uint64_t bound, int max_blocks, bool count) {
+    if (S.nl == 0) return;
+    if (count || S.profile) launch_shadow<true>(st, accel, S, P, C, g, bound, max_blocks);
+    else launch_shadow<false>(st, accel, S, P, C, g, bound, max_blocks);
 }
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                int max_blocks) {
     hipLaunchKernelGGL(k_shade, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
+}
+void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C) {
+    hipLaunchKernelGGL(k_reduce_stats, dim3(10), dim3(256), 0, st, P, C);
 }
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks) {

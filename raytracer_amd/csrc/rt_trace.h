@@ -9,8 +9,8 @@
 
 #define RT_DMIN 0.001   // self-intersection window, a SQUARED distance (src/raytrace.cpp:139, :536)
 
-__device__ inline uint32_t fbits(float f) { return __float_as_uint(f); }
-__device__ inline float bitsf(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
 
 // ---------------------------------------------------------------- spheres
 // One iteration of RayTrace::intersectSpheres (src/raytrace.cpp:226-299) for one
@@ -18,7 +18,7 @@ __device__ inline float bitsf(uint32_t u) { return __uint_as_float(u); }
 // candidate's squared distance (a float widened to double in the reference), tf
 // the float ray parameter that produced it.
 // Window (src/raytrace.cpp:245,:258,:273,:286): t > 0 && d > dmin && d < dmax, strict.
-__device__ inline bool sphere_test(F3 o, F3 d, double dd, float4 s, float dmax, float& d2out,
+__device__ __forceinline__ bool sphere_test(F3 o, F3 d, double dd, float4 s, float dmax, float& d2out,
                                    float& tfout) {
     F3 ec = o - f3(s);
     double dec = (double)dot3(d, ec);
@@ -59,7 +59,7 @@ struct TriHit {
 // where beta + gamma <= 1 needs the rounded quotients themselves.  Any
 // non-finite or zero determinant takes the literal path.
 // Window (src/raytrace.cpp:332): reject when dist < dmin || dist > dmax (inclusive).
-__device__ inline bool tri_test(F3 o, F3 d, F3 a, F3 ab, F3 ac, float dmax, TriHit& h) {
+__device__ __forceinline__ bool tri_test(F3 o, F3 d, F3 a, F3 ab, F3 ac, float dmax, TriHit& h) {
     F3 ae = a - o;
     float m1 = ac.y * d.z - d.y * ac.z;
     float m2 = ac.z * d.x - d.z * ac.x;
@@ -102,7 +102,7 @@ __device__ inline bool tri_test(F3 o, F3 d, F3 a, F3 ab, F3 ac, float dmax, TriH
 // Shading normal of a triangle hit (src/raytrace.cpp:336-358): flat normals flip
 // to face the ray; smooth normals flip per vertex, then blend as
 // n0*beta + n1*gamma + n2*alpha (the reference's pairing) and normalise.
-__device__ inline F3 tri_normal(const float4* __restrict__ tn, int flag, F3 rd, const TriHit& h) {
+__device__ __forceinline__ F3 tri_normal(const float4* __restrict__ tn, int flag, F3 rd, const TriHit& h) {
     F3 n0 = f3(tn[0]);
     if (!flag) {
         double ang = (double)dot3(n0, rd);
@@ -117,7 +117,7 @@ __device__ inline F3 tri_normal(const float4* __restrict__ tn, int flag, F3 rd, 
     return norm3(((m1 * (float)h.beta) + (m2 * (float)h.gamma)) + (m3 * (float)alpha));
 }
 
-__device__ inline void tri_load(const float4* __restrict__ t, F3& a, F3& ab, F3& ac) {
+__device__ __forceinline__ void tri_load(const float4* __restrict__ t, F3& a, F3& ab, F3& ac) {
     float4 q0 = t[0], q1 = t[1], q2 = t[2];
     a = f3(q0.x, q0.y, q0.z);
     ab = f3(q0.w, q1.x, q1.y);
@@ -135,7 +135,7 @@ struct HitUV {
 // ---------------------------------------------------------------- hit record
 // Re-evaluates the winning primitive with the same arithmetic and writes the
 // Intersect fields the shading needs (src/raytrace.cpp:246-255, :329-387).
-__device__ inline void make_hit(const DScene& S, F3 o, F3 d, double dd, int prim, float dmax,
+__device__ __forceinline__ void make_hit(const DScene& S, F3 o, F3 d, double dd, int prim, float dmax,
                                 F3& point, F3& normal, int& mat) {
     if (prim < S.ns) {
         float4 s = S.sph[prim];
@@ -160,7 +160,7 @@ __device__ inline void make_hit(const DScene& S, F3 o, F3 d, double dd, int prim
 
 // Same record from the values the walk kept.  Smooth triangles blend their normals with
 // the DOUBLE barycentrics (src/raytrace.cpp:344-357), so they are re-tested.
-__device__ inline void make_hit_uv(const DScene& S, F3 o, F3 d, int prim, HitUV uv, F3& point, F3& normal,
+__device__ __forceinline__ void make_hit_uv(const DScene& S, F3 o, F3 d, int prim, HitUV uv, F3& point, F3& normal,
                                    int& mat) {
     if (prim < S.ns) {
         float4 s = S.sph[prim];
@@ -191,7 +191,7 @@ __device__ inline void make_hit_uv(const DScene& S, F3 o, F3 d, int prim, HitUV 
 // ---------------------------------------------------------------- lights
 // Direction to the light and squared distance bound of the shadow query
 // (src/raytrace.cpp:523-534).
-__device__ inline void light_dir(const DLight& L, F3 point, F3& I, float& dist2) {
+__device__ __forceinline__ void light_dir(const DLight& L, F3 point, F3& I, float& dist2) {
     if (L.type == 1) {                       // DIRECTIONAL
         I = norm3(f3(L.dx, L.dy, L.dz) * -1.0f);
         dist2 = __builtin_inff();
