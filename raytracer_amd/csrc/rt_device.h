@@ -98,7 +98,9 @@ struct DScene {
 #define RT_NQ 256
 #define RT_WQ_STRIDE 32                                  // uint32 per counter = 128 bytes
 #define RT_WQ_LAUNCH (RT_NQ * RT_WQ_STRIDE)              // uint32 per launch
-#define RT_WQ_PROBES 8                                   // neighbours tried once the home queue is empty
+#ifndef RT_WQ_PROBES
+#define RT_WQ_PROBES 2                                   // neighbours tried once the home queue is empty
+#endif
 
 struct DPool {
     // per ray, all generations of the batch

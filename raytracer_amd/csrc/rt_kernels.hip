@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t gen_size(const DCounters* __restrict__ c, in
 // finish: measured, the average wave of the closest-hit kernel was alive for only 65 % of
 // the launch.  Here every wave draws the next group of its home queue with one atomic
 // (issued BEFORE the current group is processed, so its latency is hidden), and once
-// the home queue is empty it helps RT_WQ_PROBES neighbours.  The group a wave processes
+// the home queue is empty it helps RT_WQ_PROBES neighbours (more probes only lengthen the tail).  The group a wave processes
 // only selects WHICH rays it works on; results land at positions fixed by the ray index.
 __device__ __forceinline__ uint32_t wq_grab(uint32_t* counter, uint32_t lane) {
     uint32_t k = 0;
