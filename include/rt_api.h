@@ -94,7 +94,8 @@ typedef struct rt_options {
     int32_t accel;             /* RT_ACCEL_*; AUTO = brute force (LDS-staged) for small
                                   scenes, LBVH above lbvh_threshold primitives          */
     int32_t lbvh_threshold;    /* 0 = default (64)                                      */
-    int32_t batch_samples;     /* pixel-samples per wavefront batch, 0 = default (32 Mi)*/
+    int32_t batch_samples;     /* pixel-samples per wavefront batch, 0 = default (128 Mi,
+                                  halved while the pool does not fit in device memory)   */
     int64_t pool_rays;         /* ray-pool capacity per batch, 0 = default (4 x batch)  */
     void* stream;              /* hipStream_t to run on, NULL = a stream the ctx owns   */
 } rt_options;

@@ -580,19 +580,32 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     int rc = set_partition(c, rank, world);
     if (rc != RT_OK) return rc;
     const uint32_t spp = (uint32_t)c->cam.spp;
-    uint64_t want_samples = c->opt.batch_samples > 0 ? (uint64_t)c->opt.batch_samples : (32ull << 20);
+    // Batch = as many samples as one pass of the pipeline takes.  Large on purpose: the late, thin
+    // generations of a batch cannot run faster than their longest walks, so their launches have a floor
+    // of ~0.1 ms each whatever they hold; one 128 Mi batch (about 75 GB of pool, a quarter of this GPU's
+    // HBM) renders the K3 frame in 16 ms where four 32 Mi batches take 20.
+    uint64_t want_samples = c->opt.batch_samples > 0 ? (uint64_t)c->opt.batch_samples : (128ull << 20);
     if (const char* e = getenv("RT_BATCH_SAMPLES")) want_samples = strtoull(e, nullptr, 10);
     uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
     if (per_tile > 0x7FFFFFFFull) { rt_set_error("sample_rate too large for one tile per batch"); return RT_ERR_UNSUPPORTED; }
-    uint32_t tiles_per_batch = (uint32_t)std::max<uint64_t>(1, want_samples / per_tile);
     uint32_t total_tiles = (uint32_t)c->tiles.size();
-    tiles_per_batch = std::min(tiles_per_batch, std::max(1u, total_tiles));
-    uint64_t batch_samples = (uint64_t)tiles_per_batch * per_tile;
-    uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 4 * batch_samples;
-    capacity = std::max(capacity, batch_samples);
-    if (c->opt.pool_rays <= 0) capacity = std::max(capacity, c->pool_capacity);   // keep what earlier frames grew
-    rc = ensure_pool(c, capacity, batch_samples);
-    if (rc != RT_OK) return rc;
+    uint32_t tiles_per_batch = 1;
+    for (;;) {
+        tiles_per_batch = (uint32_t)std::max<uint64_t>(1, want_samples / per_tile);
+        tiles_per_batch = std::min(tiles_per_batch, std::max(1u, total_tiles));
+        uint64_t batch_samples = (uint64_t)tiles_per_batch * per_tile;
+        uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 4 * batch_samples;
+        capacity = std::max(capacity, batch_samples);
+        if (c->opt.pool_rays <= 0) capacity = std::max(capacity, c->pool_capacity);   // keep what earlier frames grew
+        capacity = std::min<uint64_t>(capacity, 0x7FFFFFF0ull);
+        rc = ensure_pool(c, capacity, batch_samples);
+        if (rc == RT_OK) break;
+        // not enough device memory for this batch size: halve it (the image does not depend on it)
+        if (rc != RT_ERR_NOMEM || want_samples <= (4ull << 20) || tiles_per_batch <= 1) return rc;
+        (void)hipGetLastError();
+        free_pool(c);
+        want_samples /= 2;
+    }
     if (!c->tuned && (rc = calibrate(c, tiles_per_batch)) != RT_OK) return rc;
 
     StageTimes tm;
