@@ -474,8 +474,8 @@ static void adopt_tree(rt_ctx* c, bool use_alt) {
 
 // Picks the hierarchy (Karras or PLOC, when both were built) and, per ray generation, the
 // faster of the two LBVH walks for the extend and the shadow kernel, by timing them on a
-// sample of the frame: as many tiles as one batch holds, evenly spaced over the rank's
-// share of the film, all their samples.  Every combination gives bit-identical results, so
+// sample of the frame: tiles worth up to 32 Mi samples (at most one batch), evenly spaced over
+// the rank's share of the film, all their samples.  Every combination gives bit-identical results, so
 // only speed is at stake; the sample's pixels are discarded.  The sample is a whole batch
 // on purpose: a small one measures latency, not throughput, and picks the per-lane walk
 // where the packet walk wins at scale.  Once per loaded scene.
@@ -499,7 +499,8 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     uint32_t* d_pick = nullptr;
     static float te[2][4][RT_MAX_GEN + 1], tsh[2][4][RT_MAX_GEN + 1];
     bool ok = false;
-    uint32_t n = std::min(total, std::max(1u, tiles_per_batch));
+    // at most 32 Mi samples: enough to be in the throughput regime, and about one extra K3 frame in all
+    uint32_t n = std::min(total, std::max(1u, std::min<uint32_t>(tiles_per_batch, (uint32_t)std::max<uint64_t>(1, (32ull << 20) / per_tile))));
     for (; !ok && n >= 1; n /= 2) {
         std::vector<uint32_t> pick(n);
         for (uint32_t k = 0; k < n; k++) pick[k] = c->tiles[(uint64_t)k * total / n];

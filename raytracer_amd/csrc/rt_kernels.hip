@@ -5,8 +5,8 @@
 // The reference recursion (evaluateRayTree -> getColor -> evaluateRayTree,
 // src/raytrace.cpp:131-151, :488-632) is unrolled generation by generation: all
 // rays of recursion depth g form one contiguous slice of a ray pool; the shade
-// kernel of depth g appends the reflection / refraction rays of depth g+1 with
-// wave64 ballot + prefix-count compaction (one atomic per wave).  Colours flow
+// kernel of depth g appends the reflection / refraction rays of depth g+1 at the
+// offsets a prefix sum over wave64 ballots assigned (no atomics).  Colours flow
 // back bottom-up: a ray adds spec*child and trans*child to its local colour in
 // the reference's order (:594-596, :625-627) and hands the sum to its parent's
 // slot, so every float operation of the recursion happens exactly once and in
@@ -660,9 +660,6 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
         }
     } else if (inrange) {
         if (active) deliver(P, g, R.parent, R.slot, S.bg);
-#ifdef EXP_LOC
-        P.loc[r] = make_float4(0, 0, 0, 0);
-#endif
     }
     unsigned long long mh = __ballot(hit), m1 = __ballot(refl), m2 = __ballot(refr);
     if ((threadIdx.x & 63) == 0 && inrange) {

@@ -249,6 +249,24 @@ def test_every_walk_renders_the_same_image(tracer, monkeypatch, name, kw):
         assert st.rays == st0.rays, label
 
 
+def test_work_counters_are_optional_and_do_not_change_the_image(tracer):
+    scene = load_scene("dragon").copy(width=128, height=96, spp=2)
+    tracer.load_scene(scene)
+    rgb0, f0, st0 = tracer.render(want_float=True)
+    assert sum(st0.nodes_visited) == 0 and sum(st0.tri_tests) == 0        # off by default
+    tracer.set_work_counters(True)
+    try:
+        rgb1, f1, st1 = tracer.render(want_float=True)
+    finally:
+        tracer.set_work_counters(False)
+    assert np.array_equal(bits(f0), bits(f1)) and np.array_equal(rgb0, rgb1)
+    assert st1.rays == st0.rays
+    assert st1.nodes_visited[0] > 0 and st1.tri_tests[0] > 0 and st1.lane_node_tests[0] >= st1.nodes_visited[0]
+    assert st1.nodes_visited[1] > 0                                        # shadow rays walk the tree too
+    rgb2, f2, st2 = tracer.render(want_float=True)
+    assert sum(st2.nodes_visited) == 0
+
+
 def test_edge_cases(tracer):
     # empty scene: background everywhere, no secondary or shadow rays
     s = ra.SceneArrays(width=70, height=33, background=np.array([.25, .5, 1], np.float32))
