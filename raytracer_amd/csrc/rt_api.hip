@@ -72,6 +72,8 @@ struct rt_ctx {
     float4* d_nodes = nullptr; int* d_prim_idx = nullptr; float4* d_leaf = nullptr;
     // second hierarchy over the same leaves (PLOC), until calibration has picked one of the two
     float4* d_nodes_alt = nullptr; int depth_alt = 0;
+    // 4-wide collapses of the two hierarchies (per-lane walks only); nullptr where not built
+    float4* d_wide = nullptr; float4* d_wide_alt = nullptr;
 
     // ray pool
     DPool P{};
@@ -93,9 +95,9 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c) {
     hipFree(c->d_sph); hipFree(c->d_sph_mat); hipFree(c->d_tri); hipFree(c->d_tri_n);
-    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_nodes_alt); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
+    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_nodes_alt); hipFree(c->d_wide); hipFree(c->d_wide_alt); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
     c->d_sph = nullptr; c->d_sph_mat = nullptr; c->d_tri = nullptr; c->d_tri_n = nullptr;
-    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_nodes_alt = nullptr; c->d_prim_idx = nullptr; c->d_leaf = nullptr;
+    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_nodes_alt = nullptr; c->d_wide = nullptr; c->d_wide_alt = nullptr; c->d_prim_idx = nullptr; c->d_leaf = nullptr;
     c->has_scene = false;
 }
 static void free_pool(rt_ctx* c) {
@@ -122,11 +124,13 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     if (const char* e = getenv("RT_COUNT_WORK")) c->count_work = atoi(e) != 0;
     if (const char* e = getenv("RT_PACKET_GENS")) {
         c->forced_modes = true;
-        for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_extend[g] = g < atoi(e) ? 3 : 2;
+        const int lane_mode = getenv("RT_LANE_WIDE") ? 4 : 2;      // RT_LANE_WIDE: the per-lane walks use the 4-wide tree
+        for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_extend[g] = g < atoi(e) ? 3 : lane_mode;
     }
     if (const char* e = getenv("RT_PACKET_SHADOW_GENS")) {
         c->forced_modes = true;
-        for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_shadow[g] = g < atoi(e) ? 3 : 2;
+        const int lane_mode = getenv("RT_LANE_WIDE") ? 4 : 2;
+        for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_shadow[g] = g < atoi(e) ? 3 : lane_mode;
     }
     c->device = c->opt.device;
     if (c->device < 0 || c->device >= ndev) { delete c; rt_set_error("device ordinal out of range"); return RT_ERR_INVALID; }
@@ -280,9 +284,9 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
         if (const char* e = getenv("RT_PLOC_RADIUS")) radius = std::max(0, std::min(256, atoi(e)));
         int depth_k = 0;
         hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf,
-                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt);
+                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt, &c->d_wide, &c->d_wide_alt);
         if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
-        S.nodes = c->d_nodes; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = 0; S.depth = depth_k;
+        S.nodes = c->d_nodes; S.nodes4 = c->d_wide; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = 0; S.depth = depth_k;
         if (getenv("RT_VERBOSE"))
             fprintf(stderr, "[rt bvh] %d primitives; Karras depth %d; PLOC(radius %d) depth %d%s\n", S.n_prims, depth_k, radius,
                     c->depth_alt, c->d_nodes_alt ? "" : " (not built)");
@@ -416,6 +420,8 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
         if (c->accel == RT_ACCEL_LBVH) { acc_e = c->mode_extend[g]; acc_s = c->mode_shadow[g]; }
+        if (acc_e == 4 && !S.nodes4) acc_e = 2;
+        if (acc_s == 4 && !S.nodes4) acc_s = 2;
         rtk_extend(st, acc_e, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work);
         tm.mark(0);
         rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
@@ -461,19 +467,23 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
 
 // Keeps one of the two hierarchies built at load time and frees the other.
 static void adopt_tree(rt_ctx* c, bool use_alt) {
-    if (!c->d_nodes_alt) return;
-    if (use_alt) {
-        std::swap(c->d_nodes, c->d_nodes_alt);
-        c->S.depth = c->depth_alt;
+    if (c->d_nodes_alt) {
+        if (use_alt) {
+            std::swap(c->d_nodes, c->d_nodes_alt);
+            std::swap(c->d_wide, c->d_wide_alt);
+            c->S.depth = c->depth_alt;
+        }
+        hipFree(c->d_nodes_alt); hipFree(c->d_wide_alt);
+        c->d_nodes_alt = nullptr; c->d_wide_alt = nullptr;
     }
-    hipFree(c->d_nodes_alt);
-    c->d_nodes_alt = nullptr;
     c->S.nodes = c->d_nodes;
+    c->S.nodes4 = c->d_wide;
     c->S.root = 0;
 }
 
 // Picks the hierarchy (Karras or PLOC, when both were built) and, per ray generation, the
-// faster of the two LBVH walks for the extend and the shadow kernel, by timing them on a
+// fastest of the walks (2 per-lane, 3 wave packet, 4 per-lane on the 4-wide collapse) for the
+// extend and the shadow kernel, by timing them on a
 // sample of the frame: tiles worth up to 32 Mi samples (at most one batch), evenly spaced over
 // the rank's share of the film, all their samples.  Every combination gives bit-identical results, so
 // only speed is at stake; the sample's pixels are discarded.  The sample is a whole batch
@@ -493,11 +503,12 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     const int G = S.max_depth + 1;
     const int ntrees = c->d_nodes_alt ? 2 : 1;
     const float4* tree_nodes[2] = {c->d_nodes, c->d_nodes_alt};
+    const float4* tree_wide[2] = {c->d_wide, c->d_wide_alt};
     const int tree_depth[2] = {S.depth, c->depth_alt};
     std::vector<hipEvent_t> ev((size_t)G * 4);
     for (auto& e : ev) hipEventCreate(&e);
     uint32_t* d_pick = nullptr;
-    static float te[2][4][RT_MAX_GEN + 1], tsh[2][4][RT_MAX_GEN + 1];
+    static float te[2][5][RT_MAX_GEN + 1], tsh[2][5][RT_MAX_GEN + 1];
     bool ok = false;
     // at most 32 Mi samples: enough to be in the throughput regime, and about one extra K3 frame in all
     uint32_t n = std::min(total, std::max(1u, std::min<uint32_t>(tiles_per_batch, (uint32_t)std::max<uint64_t>(1, (32ull << 20) / per_tile))));
@@ -510,8 +521,12 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         const uint32_t nsamples = (uint32_t)(n * per_tile);
         ok = true;
         for (int t = 0; t < ntrees && ok; t++) {
-            S.nodes = tree_nodes[t]; S.depth = tree_depth[t]; S.root = 0;
-            for (int mode = 2; mode <= 3 && ok; mode++) {
+            S.nodes = tree_nodes[t]; S.nodes4 = tree_wide[t]; S.depth = tree_depth[t]; S.root = 0;
+            for (int mode = 2; mode <= 4 && ok; mode++) {
+                if (mode == 4 && !tree_wide[t]) {
+                    for (int g = 0; g < G; g++) te[t][4][g] = tsh[t][4][g] = 1e30f;
+                    continue;
+                }
                 hipStream_t st = c->stream;
                 rtk_init_counters(st, c->d_counters, nsamples, c->P, G);
                 uint64_t bound = nsamples;
@@ -538,14 +553,15 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         }
         if (ok) break;
     }
-    S.nodes = tree_nodes[0]; S.depth = tree_depth[0];
+    S.nodes = tree_nodes[0]; S.nodes4 = tree_wide[0]; S.depth = tree_depth[0];
     for (auto& e : ev) hipEventDestroy(e);
     hipFree(d_pick);
     if (ok) {
         float best_total[2] = {0, 0};
         for (int t = 0; t < ntrees; t++)
             for (int g = 0; g < G; g++)
-                best_total[t] += std::min(te[t][2][g], te[t][3][g]) + std::min(tsh[t][2][g], tsh[t][3][g]);
+                best_total[t] += std::min(te[t][2][g], std::min(te[t][3][g], te[t][4][g])) +
+                                 std::min(tsh[t][2][g], std::min(tsh[t][3][g], tsh[t][4][g]));
         int t = (ntrees == 2 && best_total[1] < best_total[0]) ? 1 : 0;
         if (const char* e = getenv("RT_TREE")) {             // "karras" / "ploc": override the measurement
             if (!strcmp(e, "karras")) t = 0;
@@ -553,16 +569,18 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         }
         adopt_tree(c, t == 1);
         for (int g = 0; g < G; g++) {
-            c->mode_extend[g] = te[t][3][g] <= te[t][2][g] ? 3 : 2;
-            c->mode_shadow[g] = tsh[t][3][g] <= tsh[t][2][g] ? 3 : 2;
+            auto best_of = [](float lane, float packet, float wide) { return (packet <= lane && packet <= wide) ? 3 : (wide < lane ? 4 : 2); };
+            c->mode_extend[g] = (int8_t)best_of(te[t][2][g], te[t][3][g], te[t][4][g]);
+            c->mode_shadow[g] = (int8_t)best_of(tsh[t][2][g], tsh[t][3][g], tsh[t][4][g]);
         }
         if (getenv("RT_VERBOSE")) {
             fprintf(stderr, "[rt calibrate] %u tiles; traversal ms Karras %.3f", n, best_total[0]);
             if (ntrees == 2) fprintf(stderr, ", PLOC %.3f", best_total[1]);
-            fprintf(stderr, " -> %s; extend (lane/packet ms):", t ? "PLOC" : "Karras");
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, te[t][2][g], te[t][3][g], c->mode_extend[g] == 3 ? 'P' : 'L');
+            const char* tag = "?-LPW";
+            fprintf(stderr, " -> %s; extend (lane/packet/wide ms):", t ? "PLOC" : "Karras");
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, te[t][2][g], te[t][3][g], te[t][4][g] > 1e29f ? 0.0f : te[t][4][g], tag[c->mode_extend[g]]);
             fprintf(stderr, "; shadow:");
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f->%c", g, tsh[t][2][g], tsh[t][3][g], c->mode_shadow[g] == 3 ? 'P' : 'L');
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, tsh[t][2][g], tsh[t][3][g], tsh[t][4][g] > 1e29f ? 0.0f : tsh[t][4][g], tag[c->mode_shadow[g]]);
             fprintf(stderr, "\n");
         }
     } else {
@@ -750,7 +768,7 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     if (!c->has_scene) return RT_ERR_NO_SCENE;
     const bool alt = (accel & RT_ACCEL_ALT_TREE) != 0;
     accel &= ~RT_ACCEL_ALT_TREE;
-    if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH && accel != RT_ACCEL_LBVH_PACKET) return RT_ERR_INVALID;
+    if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH && accel != RT_ACCEL_LBVH_PACKET && accel != RT_ACCEL_LBVH_WIDE) return RT_ERR_INVALID;
     if (alt && (accel == RT_ACCEL_BRUTE || !c->d_nodes_alt)) {
         rt_set_error("no second hierarchy is held (none was built, or a render has already chosen)");
         return RT_ERR_UNSUPPORTED;
@@ -771,7 +789,12 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     Q_TRY(hipMemcpyAsync(d_d, d, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (dmax) Q_TRY(hipMemcpyAsync(d_m, dmax, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     DScene Sq = c->S;
-    if (alt) { Sq.nodes = c->d_nodes_alt; Sq.depth = c->depth_alt; Sq.root = 0; }
+    if (alt) { Sq.nodes = c->d_nodes_alt; Sq.nodes4 = c->d_wide_alt; Sq.depth = c->depth_alt; Sq.root = 0; }
+    if (accel == RT_ACCEL_LBVH_WIDE && !Sq.nodes4) {
+        cleanup();
+        rt_set_error("no 4-wide collapse of this hierarchy was built (tree deeper than 64)");
+        return RT_ERR_UNSUPPORTED;
+    }
     rtk_query(c->stream, accel, any_hit, Sq, n, d_o, d_d, d_m, d_p, d_d2);
     Q_TRY(hipGetLastError());
     Q_TRY(hipMemcpyAsync(prim_out, d_p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));

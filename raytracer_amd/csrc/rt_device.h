@@ -80,6 +80,7 @@ struct DScene {
     F3 bg, ambient;
     // LBVH (valid when nodes != nullptr)
     const float4* nodes;     // [n_internal][4], see rt_lbvh.hip
+    const float4* nodes4;    // 4-wide collapse of the same tree, [..][8] (nullptr if not built); root = node 0 in both
     const int* prim_idx;     // [ns+nt] sorted primitive ids (sphere i, or ns + triangle i)
     const float4* leaf;      // [ns+nt][3] primitive records in tree order, see rt_lbvh.hip
     int root;                // root reference

@@ -29,7 +29,7 @@
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES)))
 #else
 // the per-lane walks hide memory latency with waves: 5 per SIMD at the price of a few spilled dwords
-#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ACCEL == 2 ? RT_LANE_WAVES : 1, 8)))
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : 1, 8)))
 #endif
 #ifndef RT_LANE_WAVES
 #define RT_LANE_WAVES 5
@@ -238,8 +238,65 @@ __device__ __forceinline__ bool leaf_test(F3 o, F3 d, double dd, float4 l0, floa
     return hit;
 }
 
+// One inner-node step of a per-lane walk: tests the children of node `cur`, continues with the
+// nearest one that is hit and leaves the others on the lane's stack, nearest on top; with no
+// child hit the next reference comes off the stack.  Returns the next reference (>= 0 inner
+// node, < 0 leaf) or LANE_DONE when nothing is left.  WIDE: the 4-wide collapse of the tree (8
+// float4 per node: four boxes, four references), which halves the number of dependent fetches.
+#define LANE_DONE ((int)0x80000000)   // ~(2^31 - 1): never a leaf slot; also the reference of an empty wide slot
+
+__device__ __forceinline__ void order2(float& ka, int& ra, float& kb, int& rb) {   // ascending by key
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const SlabRay& R, float tmax, int* stack,
+                                               int& sp, TraceStats& ts) {
+    // counted in 64-byte records / box pairs: a wide node is two of each
+    ts.nodes += WIDE ? 2 : 1; ts.lane_nodes += WIDE ? 2 : 1;
+    if (!WIDE) {
+        const v4f* nd = (const v4f*)S.nodes + 4 * (size_t)cur;
+        v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        float tn0, tn1;
+        bool h0, h1;
+        box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
+        const int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
+        if (h0 && h1) {
+            const bool swap = tn1 < tn0;
+            if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
+            return swap ? c1 : c0;
+        }
+        if (h0) return c0;
+        if (h1) return c1;
+        return sp > 0 ? stack[--sp] : LANE_DONE;
+    } else {
+        const v4f* nd = (const v4f*)S.nodes4 + 8 * (size_t)cur;
+        v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
+        float k0, k1, k2, k3;
+        bool h0, h1, h2, h3;
+        box_pair<8>(q0, q1, q2, R, tmax, h0, h1, k0, k1);
+        box_pair<8>(q3, q4, q5, R, tmax, h2, h3, k2, k3);
+        int r0 = (int)fbits(q6.x), r1 = (int)fbits(q6.y), r2 = (int)fbits(q6.z), r3 = (int)fbits(q6.w);
+        const float inf = __builtin_inff();
+        // a missed or empty slot sorts last (an empty slot's inverted box reads as an infinite slab in the min / max test)
+        k0 = (h0 && r0 != LANE_DONE) ? k0 : inf; k1 = (h1 && r1 != LANE_DONE) ? k1 : inf;
+        k2 = (h2 && r2 != LANE_DONE) ? k2 : inf; k3 = (h3 && r3 != LANE_DONE) ? k3 : inf;
+        order2(k0, r0, k1, r1); order2(k2, r2, k3, r3);      // sorting network for four
+        order2(k0, r0, k2, r2); order2(k1, r1, k3, r3);
+        order2(k1, r1, k2, r2);
+        if (k3 < inf && sp < LBVH_STACK) stack[sp++] = r3;   // farthest first: the nearer ones come off first
+        if (k2 < inf && sp < LBVH_STACK) stack[sp++] = r2;
+        if (k1 < inf && sp < LBVH_STACK) stack[sp++] = r1;
+        if (k0 < inf) return r0;
+        return sp > 0 ? stack[--sp] : LANE_DONE;
+    }
+}
+
 // Per-lane while-while traversal with a private stack: every lane walks its own path.
-template <bool ANY>
+template <bool ANY, bool WIDE = false>
 __device__ __forceinline__ void lbvh_trace(const DScene& S, bool active, F3 o, F3 d, float dmax, int& best,
                                   float& best_d2, HitUV& uv, TraceStats& ts) {
     best = -1;
@@ -250,25 +307,10 @@ __device__ __forceinline__ void lbvh_trace(const DScene& S, bool active, F3 o, F
     float tmax = slab_tmax(R, dmax);
     int stack[LBVH_STACK];
     int sp = 0;
-    int cur = S.root;
-    const v4f* nodes = (const v4f*)S.nodes;
-    while (true) {
+    int cur = 0;                                   // both trees keep their root at node 0
+    while (cur != LANE_DONE) {
         if (cur >= 0) {
-            const v4f* nd = nodes + 4 * (size_t)cur;
-            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            ts.nodes++; ts.lane_nodes++;
-            float tn0, tn1;
-            bool h0, h1;
-            box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
-            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
-            if (h0 && h1) {
-                bool swap = tn1 < tn0;
-                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                if (sp < LBVH_STACK) stack[sp++] = farc;
-                cur = nearc;
-                continue;
-            } else if (h0) { cur = c0; continue; }
-            else if (h1) { cur = c1; continue; }
+            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stack, sp, ts);
         } else {
             const float4* lf = S.leaf + 3 * (size_t)(~cur);
             float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
@@ -286,9 +328,8 @@ __device__ __forceinline__ void lbvh_trace(const DScene& S, bool active, F3 o, F
                     tmax = slab_tmax(R, d2);
                 }
             }
+            cur = sp > 0 ? stack[--sp] : LANE_DONE;
         }
-        if (sp == 0) break;
-        cur = stack[--sp];
     }
 }
 
@@ -463,7 +504,8 @@ __device__ __forceinline__ void trace(const DScene& S, float4* lds, bool active,
                              int& best, float& best_d2, HitUV& uv, TraceStats& ts) {
     uv.a = 0; uv.b = 0;
     if (ACCEL == 1) brute_trace<ANY>(S, lds, active, o, d, dmax, best, best_d2, uv, ts);
-    else if (ACCEL == 2) lbvh_trace<ANY>(S, active, o, d, dmax, best, best_d2, uv, ts);
+    else if (ACCEL == 2) lbvh_trace<ANY, false>(S, active, o, d, dmax, best, best_d2, uv, ts);
+    else if (ACCEL == 4) lbvh_trace<ANY, true>(S, active, o, d, dmax, best, best_d2, uv, ts);
     else lbvh_trace_packet<ANY>(S, active, o, d, dmax, best, best_d2, uv, ts);
 }
 
@@ -677,7 +719,6 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
 #ifndef LEAF_MIN
 #define LEAF_MIN 12
 #endif
-#define LANE_DONE ((int)0x80000000)   // ~(2^31 - 1): never a leaf slot
 
 
 // Closest-hit walk with lane refill (see shadow_chunk for the idea): a wave owns `n` consecutive
@@ -686,11 +727,11 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
 // write their hit (or miss) records together and take the next rays of the chunk.  Rays
 // are finished out of order, so the three ballot masks of each 64-ray group are put
 // together at the end from one flag byte per ray kept in LDS (`flags`, this wave's own).
+template <bool WIDE>
 __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
                                     uint32_t gbase, uint32_t first, uint32_t n, uint8_t* flags, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const v4f* nodes = (const v4f*)S.nodes;
     enum { IDLE = 0, WALK = 1, FIN = 2 };
     uint32_t next = 64, k = lane;
     int state = IDLE;
@@ -710,7 +751,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
         dd = (double)dot3(d, d);
         R = slab_ray(o, d);
         tmax = __builtin_inff();
-        cur = S.root; sp = 0;
+        cur = 0; sp = 0;                            // both trees keep their root at node 0
         state = valid ? WALK : FIN;
     };
     if (k < n) begin(k);
@@ -718,21 +759,8 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
         if (ballot64(state != IDLE) == 0ull) break;
         const bool at_node = state == WALK && cur >= 0;
         if (at_node) {
-            const v4f* nd = nodes + 4 * (size_t)cur;
-            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            ts.nodes++; ts.lane_nodes++;
-            float tn0, tn1;
-            bool h0, h1;
-            box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
-            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
-                cur = swap ? c1 : c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else if (sp > 0) cur = stack[--sp];
-            else state = FIN;
+            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stack, sp, ts);
+            if (cur == LANE_DONE) state = FIN;
         }
         // lanes at a leaf wait until LEAF_MIN of them are (see shadow_chunk)
         const bool at_leaf = state == WALK && !at_node;
@@ -813,7 +841,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
     if (ACCEL == 1) {   // block-wide LDS staging: the whole block moves together
         for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
             extend_one<ACCEL>(S, P, G, g, start, count, gbase, base + threadIdx.x, lds, ts);
-    } else if (ACCEL == 2) {
+    } else if (ACCEL == 2 || ACCEL == 4) {
         __shared__ uint8_t flags[RT_BLOCK / 64][REFILL_GROUPS * 64];
         const uint64_t groups = ((uint64_t)count + 63) >> 6;
         const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -827,7 +855,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
         } else {
             for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + span - 1) / span, [&](uint64_t c) {
                 const uint32_t first = (uint32_t)c * span;
-                extend_chunk(S, P, G, g, start, gbase, first, min(span, count - first), flags[threadIdx.x >> 6], ts);
+                extend_chunk<ACCEL == 4>(S, P, G, g, start, gbase, first, min(span, count - first), flags[threadIdx.x >> 6], ts);
             });
         }
     } else {
@@ -947,10 +975,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int
 // idle lane takes the next item of the chunk (ballot + prefix count, no atomics), so the
 // wave stays full until the chunk runs out.  One loop iteration = one node or one leaf per
 // lane, exactly the step of lbvh_trace<true>.
+template <bool WIDE>
 __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, uint64_t first, uint64_t end, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const v4f* nodes = (const v4f*)S.nodes;
     const uint32_t nl = (uint32_t)S.nl;
     const uint32_t count = (uint32_t)(end - first);
     uint32_t next = 64;                  // wave-uniform: first item of the chunk not handed out yet
@@ -971,7 +999,7 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, ui
         dd = (double)dot3(d, d);
         R = slab_ray(o, d);
         tmax = slab_tmax(R, dmax);
-        cur = S.root;
+        cur = 0;                                    // both trees keep their root at node 0
         sp = 0;
     };
     if (alive) start(k);
@@ -979,21 +1007,8 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, ui
         int verdict = -1;                // 0: reaches the light, 1: occluded
         const bool at_node = alive && cur >= 0;
         if (at_node) {
-            const v4f* nd = nodes + 4 * (size_t)cur;
-            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            ts.nodes++; ts.lane_nodes++;
-            float tn0, tn1;
-            bool h0, h1;
-            box_pair<8>(q0, q1, q2, R, tmax, h0, h1, tn0, tn1);
-            int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;      // nearer box first: an occluder, if any, tends to be met sooner
-                if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
-                cur = swap ? c1 : c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else if (sp > 0) cur = stack[--sp];
-            else verdict = 0;
+            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stack, sp, ts);
+            if (cur == LANE_DONE) verdict = 0;
         }
         // The exact primitive test is four times the cost of a node step and only a few lanes
         // want it at any time: lanes that have reached a leaf wait until LEAF_MIN have (or
@@ -1052,7 +1067,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
     if (ACCEL == 1) {
         for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < items; base += (uint64_t)gridDim.x * blockDim.x)
             one(base + threadIdx.x);
-    } else if (ACCEL == 2) {
+    } else if (ACCEL == 2 || ACCEL == 4) {
         // chunks of several 64-item groups when there is enough work for every wave to get a few
         const uint64_t groups = (items + 63) >> 6;
         const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -1065,7 +1080,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
         } else {
             for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + span - 1) / span, [&](uint64_t c) {
                 const uint64_t first = c * span;
-                shadow_chunk(S, P, first, first + span < items ? first + span : items, ts);
+                shadow_chunk<ACCEL == 4>(S, P, first, first + span < items ? first + span : items, ts);
             });
         }
     } else {
@@ -1335,13 +1350,15 @@ static int resident_blocks(K kernel, int max_blocks) {
 template <bool COUNT>
 static void launch_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const GenSrc& G,
                           int g, uint64_t bound, int max_blocks) {
-    static int res[4] = {0, 0, 0, 0};
+    static int res[5] = {0, 0, 0, 0, 0};
     if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_extend<1, COUNT>, max_blocks)
                                  : accel == 2 ? resident_blocks(k_extend<2, COUNT>, max_blocks)
+                                 : accel == 4 ? resident_blocks(k_extend<4, COUNT>, max_blocks)
                                               : resident_blocks(k_extend<3, COUNT>, max_blocks);
     dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL((k_extend<1, COUNT>), grid, block, 0, st, S, P, C, G, g);
     else if (accel == 2) hipLaunchKernelGGL((k_extend<2, COUNT>), grid, block, 0, st, S, P, C, G, g);
+    else if (accel == 4) hipLaunchKernelGGL((k_extend<4, COUNT>), grid, block, 0, st, S, P, C, G, g);
     else hipLaunchKernelGGL((k_extend<3, COUNT>), grid, block, 0, st, S, P, C, G, g);
 }
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
@@ -1361,13 +1378,15 @@ void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t b
 template <bool COUNT>
 static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                           uint64_t bound, int max_blocks) {
-    static int res[4] = {0, 0, 0, 0};
+    static int res[5] = {0, 0, 0, 0, 0};
     if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_shadow<1, COUNT>, max_blocks)
                                  : accel == 2 ? resident_blocks(k_shadow<2, COUNT>, max_blocks)
+                                 : accel == 4 ? resident_blocks(k_shadow<4, COUNT>, max_blocks)
                                               : resident_blocks(k_shadow<3, COUNT>, max_blocks);
     dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL((k_shadow<1, COUNT>), grid, block, 0, st, S, P, C, g);
     else if (accel == 2) hipLaunchKernelGGL((k_shadow<2, COUNT>), grid, block, 0, st, S, P, C, g);
+    else if (accel == 4) hipLaunchKernelGGL((k_shadow<4, COUNT>), grid, block, 0, st, S, P, C, g);
     else hipLaunchKernelGGL((k_shadow<3, COUNT>), grid, block, 0, st, S, P, C, g);
 }
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
@@ -1406,6 +1425,9 @@ void rtk_query(hipStream_t st, int accel, int any_hit, const DScene& S, int64_t 
     } else if (accel == 2) {
         if (any_hit) hipLaunchKernelGGL((k_query<2, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
         else hipLaunchKernelGGL((k_query<2, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+    } else if (accel == 4) {
+        if (any_hit) hipLaunchKernelGGL((k_query<4, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+        else hipLaunchKernelGGL((k_query<4, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
     } else {
         if (any_hit) hipLaunchKernelGGL((k_query<3, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
         else hipLaunchKernelGGL((k_query<3, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);

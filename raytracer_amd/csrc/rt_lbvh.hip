@@ -380,18 +380,97 @@ static int ploc_build(hipStream_t st, const Box* boxes, const uint32_t* sorted, 
     return (int)hipSuccess;
 }
 
+// ---------------------------------------------------------------- 4-wide collapse
+// A per-lane walk is a chain of dependent fetches; folding every second level of the binary
+// tree into its parent halves the chain.  Inner nodes at even depth survive; each takes the
+// children of its (odd-depth) inner children, or the child itself where that is a leaf: up
+// to four entries.  Node = 8 float4: 4 boxes as (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z), then the
+// 4 references (>= 0 wide node, < 0 leaf ~slot, RT_REF_NONE empty slot with an inverted box).
+// Ids are the binary ids compacted (prefix sum), so the layout keeps its locality.
+#define RT_REF_NONE ((int)0x80000000)
+
+__global__ void k_w4_parent(const float4* nodes, int m, int* parent) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m) return;
+    float4 refs = nodes[4 * (size_t)v + 3];
+    int c0 = __float_as_int(refs.x), c1 = __float_as_int(refs.y);
+    if (c0 >= 0) parent[c0] = v;
+    if (c1 >= 0) parent[c1] = v;
+}
+__global__ void k_w4_flag(const int* parent, int m, int root, uint32_t* flag) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m) return;
+    int d = 0;
+    for (int a = v; a != root; a = parent[a]) d++;
+    flag[v] = (d & 1) ? 0u : 1u;
+}
+__device__ inline void w4_entry(float* dst, int* refs, int k, const float* box, int ref) {
+    for (int t = 0; t < 6; t++) dst[6 * k + t] = box[t];
+    refs[k] = ref;
+}
+__global__ void k_w4_collapse(const float4* nodes, int m, const uint32_t* flag, const uint32_t* idx, float4* out) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m || !flag[v]) return;
+    const float* src = (const float*)(nodes + 4 * (size_t)v);
+    float box[24]; int refs[4];
+    int k = 0;
+    for (int s = 0; s < 2; s++) {
+        int c = __float_as_int(src[12 + s]);
+        if (c < 0) { w4_entry(box, refs, k++, src + 6 * s, c); continue; }
+        const float* cs = (const float*)(nodes + 4 * (size_t)c);
+        for (int t = 0; t < 2; t++) {
+            int g = __float_as_int(cs[12 + t]);
+            w4_entry(box, refs, k++, cs + 6 * t, g < 0 ? g : (int)idx[g]);
+        }
+    }
+    const float none[6] = {__builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff()};
+    for (; k < 4; k++) w4_entry(box, refs, k, none, RT_REF_NONE);
+    float4* dst = out + 8 * (size_t)idx[v];
+    for (int q = 0; q < 6; q++) dst[q] = make_float4(box[4 * q], box[4 * q + 1], box[4 * q + 2], box[4 * q + 3]);
+    dst[6] = make_float4(__int_as_float(refs[0]), __int_as_float(refs[1]), __int_as_float(refs[2]), __int_as_float(refs[3]));
+    dst[7] = make_float4(0, 0, 0, 0);
+}
+
+// nodes: binary tree of m inner nodes, root 0.  -> *out (8 float4 per wide node, root 0), or nullptr on failure.
+static void collapse4(hipStream_t st, const float4* nodes, int m, float4** out) {
+    *out = nullptr;
+    int* parent = nullptr; uint32_t *flag = nullptr, *idx = nullptr; void* tmp = nullptr; float4* wide = nullptr;
+    auto cleanup = [&]() { (void)hipFree(parent); (void)hipFree(flag); (void)hipFree(idx); (void)hipFree(tmp); };
+    auto fail = [&]() { cleanup(); (void)hipFree(wide); (void)hipGetLastError(); };
+    if (hipMalloc(&parent, (size_t)m * 4) != hipSuccess || hipMalloc(&flag, (size_t)m * 4) != hipSuccess ||
+        hipMalloc(&idx, (size_t)m * 4) != hipSuccess) return fail();
+    dim3 grid((m + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_w4_parent, grid, block, 0, st, nodes, m, parent);
+    hipLaunchKernelGGL(k_w4_flag, grid, block, 0, st, parent, m, 0, flag);
+    size_t tmp_bytes = 0;
+    if (rocprim::exclusive_scan(nullptr, tmp_bytes, flag, idx, 0u, (size_t)m, rocprim::plus<uint32_t>(), st) != hipSuccess) return fail();
+    if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) return fail();
+    if (rocprim::exclusive_scan(tmp, tmp_bytes, flag, idx, 0u, (size_t)m, rocprim::plus<uint32_t>(), st) != hipSuccess) return fail();
+    uint32_t last[2] = {0, 0};
+    if (hipMemcpyAsync(&last[0], flag + (m - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&last[1], idx + (m - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return fail();
+    const size_t m4 = (size_t)last[0] + last[1];
+    if (m4 < 1 || hipMalloc(&wide, m4 * 8 * sizeof(float4)) != hipSuccess) return fail();
+    hipLaunchKernelGGL(k_w4_collapse, grid, block, 0, st, nodes, m, flag, idx, wide);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
+    cleanup();
+    *out = wide;
+}
+
 #define L_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(vals2); (void)hipFree(leaf); return (int)e_; } } while (0)
 
-// Builds the Karras hierarchy (nodes_out, at most 95 deep) and, when ploc_radius > 0, a PLOC
-// hierarchy over the same Morton order (ploc_out; nullptr if it failed or came out deeper
+// Builds the Karras hierarchy (nodes_out, at most 95 deep; wide_out = its 4-wide collapse or nullptr)
+// and, when ploc_radius > 0, a PLOC hierarchy over the same Morton order (ploc_out; nullptr if it failed or came out deeper
 // than the 64-entry stacks of the fast walks allow).  Both share the leaf records and have
 // their root at node 0; which one traverses faster depends on the scene and is measured
 // by the caller.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
               int** prim_idx_out, float4** leaf_out, int* depth, int ploc_radius, float4** ploc_out,
-              int* ploc_depth) {
+              int* ploc_depth, float4** wide_out, float4** ploc_wide_out) {
     int n = ns + nt;
     *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *ploc_out = nullptr; *ploc_depth = 0;
+    *wide_out = nullptr; *ploc_wide_out = nullptr;
     if (n < 2) return (int)hipErrorInvalidValue;
     Box* boxes = nullptr; uint32_t* scene = nullptr;
     unsigned long long *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;
@@ -435,11 +514,14 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
         if (hipMalloc(&pn, (size_t)(n - 1) * 4 * sizeof(float4)) == hipSuccess &&
             ploc_build(st, boxes, vals2, n, ploc_radius, pn, &r, &d) == (int)hipSuccess && d <= 64) {
             *ploc_out = pn; *ploc_depth = d;
+            collapse4(st, pn, n - 1, ploc_wide_out);
         } else {
             (void)hipFree(pn);
             (void)hipGetLastError();
         }
     }
+    // 4-wide versions for the per-lane walks (their stacks hold up to 3 entries per wide level: depth <= 64)
+    if (*depth <= 64) collapse4(st, nodes, n - 1, wide_out);
     L_TRY(hipGetLastError());
     L_TRY(hipStreamSynchronize(st));
     cleanup();

@@ -85,9 +85,10 @@ def test_primary_rays_and_closest_hits_known_answers(oracle, tracer, kat, key, s
         assert np.array_equal(d2[hit].astype(np.float64), ref_hit[hit, 4])   # reference dist (squared)
 
 
-# every walk of every hierarchy: Karras per-lane / packet, PLOC per-lane / packet
-TREE_WALKS = (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET,
-              ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_PACKET | ra.RT_ACCEL_ALT_TREE)
+# every walk of every hierarchy: per-lane / packet / per-lane 4-wide, on the Karras and on the PLOC tree
+TREE_WALKS = (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE,
+              ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_PACKET | ra.RT_ACCEL_ALT_TREE,
+              ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE)
 
 
 def _random_rays(scene, n, rng):
@@ -232,12 +233,15 @@ def test_every_walk_renders_the_same_image(tracer, monkeypatch, name, kw):
     tracer.load_scene(scene)
     rgb0, f0, st0 = tracer.render(want_float=True)
     images = {}
-    for label, n in (("lane", "0"), ("packet", "99")):
+    for label, n, wide in (("lane", "0", False), ("lane-wide", "0", True), ("packet", "99", False)):
         monkeypatch.setenv("RT_PACKET_GENS", n)
         monkeypatch.setenv("RT_PACKET_SHADOW_GENS", n)
+        if wide:
+            monkeypatch.setenv("RT_LANE_WIDE", "1")
         with ra.Tracer(device=0, accel=ra.RT_ACCEL_LBVH) as t:
             t.load_scene(scene)
             images[label] = t.render(want_float=True)
+        monkeypatch.delenv("RT_LANE_WIDE", raising=False)
     monkeypatch.delenv("RT_PACKET_GENS")
     monkeypatch.delenv("RT_PACKET_SHADOW_GENS")
     with ra.Tracer(device=0, accel=ra.RT_ACCEL_BRUTE) as t:
