@@ -63,6 +63,7 @@ struct rt_ctx {
     // incoherent ones the per-lane walk); RT_PACKET_GENS / RT_PACKET_SHADOW_GENS force it.
     int8_t mode_extend[RT_MAX_GEN + 1], mode_shadow[RT_MAX_GEN + 1];
     bool tuned = false, forced_modes = false;
+    uint32_t tiles_cap = 0;    // batches of this scene that overflowed a pool that could not grow were split: keep to that size
     bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
     DScene S{};
     DCamera cam{};
@@ -295,6 +296,7 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     }
     c->accel = accel;
     c->tuned = false;
+    c->tiles_cap = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_scene = true;
     return RT_OK;
@@ -604,7 +606,10 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     // of ~0.1 ms each whatever they hold; one 128 Mi batch (about 75 GB of pool, a quarter of this GPU's
     // HBM) renders the K3 frame in 16 ms where four 32 Mi batches take 20.
     uint64_t want_samples = c->opt.batch_samples > 0 ? (uint64_t)c->opt.batch_samples : (128ull << 20);
-    if (const char* e = getenv("RT_BATCH_SAMPLES")) want_samples = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("RT_BATCH_SAMPLES")) {
+        uint64_t v = strtoull(e, nullptr, 10);
+        if (v > 0) want_samples = v;
+    }
     uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
     if (per_tile > 0x7FFFFFFFull) { rt_set_error("sample_rate too large for one tile per batch"); return RT_ERR_UNSUPPORTED; }
     uint32_t total_tiles = (uint32_t)c->tiles.size();
@@ -612,6 +617,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     for (;;) {
         tiles_per_batch = (uint32_t)std::max<uint64_t>(1, want_samples / per_tile);
         tiles_per_batch = std::min(tiles_per_batch, std::max(1u, total_tiles));
+        if (c->tiles_cap) tiles_per_batch = std::min(tiles_per_batch, c->tiles_cap);
         uint64_t batch_samples = (uint64_t)tiles_per_batch * per_tile;
         uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 4 * batch_samples;
         capacity = std::max(capacity, batch_samples);
@@ -663,6 +669,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
                 uint32_t h = n / 2;
                 work.push_back({t0 + h, n - h});
                 work.push_back({t0, h});
+                c->tiles_cap = c->tiles_cap ? std::min(c->tiles_cap, n - h) : n - h;   // later batches and frames start there
             }
             continue;
         }
