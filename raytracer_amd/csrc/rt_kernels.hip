@@ -29,10 +29,13 @@
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES)))
 #else
 // the per-lane walks hide memory latency with waves: 5 per SIMD at the price of a few spilled dwords
-#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : 1, 8)))
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : (ACCEL == 3 ? RT_PACKET_WAVES : 1), 8)))
 #endif
 #ifndef RT_LANE_WAVES
 #define RT_LANE_WAVES 5
+#endif
+#ifndef RT_PACKET_WAVES
+#define RT_PACKET_WAVES 6
 #endif
 
 #include <algorithm>
