@@ -58,7 +58,7 @@ struct rt_ctx {
     // scene
     bool has_scene = false;
     int accel = RT_ACCEL_BRUTE;
-    // LBVH walk per generation: 2 = per-lane, 3 = wave packet.  Chosen by calibrate() from
+    // LBVH walk per generation: 2 = per-lane, 3 = wave packet, 4 = per-lane on the 4-wide collapse.  Chosen by calibrate() from
     // measured kernel times on a sample of the frame (coherent rays favour the packet walk,
     // incoherent ones the per-lane walk); RT_PACKET_GENS / RT_PACKET_SHADOW_GENS force it.
     int8_t mode_extend[RT_MAX_GEN + 1], mode_shadow[RT_MAX_GEN + 1];
@@ -119,7 +119,9 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
         rt_set_error("no HIP device is visible; this library has no CPU fallback");
         return RT_ERR_NO_DEVICE;
     }
-    rt_ctx* c = new rt_ctx();
+    // owned until the last step succeeds: any early return below releases what was created so far
+    struct Guard { rt_ctx* c; ~Guard() { if (c) rt_destroy(c); } } guard{new rt_ctx()};
+    rt_ctx* c = guard.c;
     if (opt) c->opt = *opt;
     for (int g = 0; g <= RT_MAX_GEN; g++) { c->mode_extend[g] = 3; c->mode_shadow[g] = 3; }
     if (const char* e = getenv("RT_COUNT_WORK")) c->count_work = atoi(e) != 0;
@@ -134,7 +136,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
         for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_shadow[g] = g < atoi(e) ? 3 : lane_mode;
     }
     c->device = c->opt.device;
-    if (c->device < 0 || c->device >= ndev) { delete c; rt_set_error("device ordinal out of range"); return RT_ERR_INVALID; }
+    if (c->device < 0 || c->device >= ndev) { c->device = 0; rt_set_error("device ordinal out of range"); return RT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(c->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -145,6 +147,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     HIP_TRY(hipMalloc(&c->d_counters, sizeof(DCounters)));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    guard.c = nullptr;
     *out = c;
     return RT_OK;
 }
@@ -152,7 +155,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
 extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     free_scene(c);
     free_pool(c);
     hipFree(c->d_counters); hipFree(c->d_tiles); hipFree(c->d_rowbase); hipFree(c->d_rgb); hipFree(c->d_rgbf);
@@ -207,6 +210,12 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     if (s->width <= 0 || s->height <= 0 || s->spp <= 0 || s->n_spheres < 0 || s->n_triangles < 0 ||
         s->n_lights < 0 || s->n_materials < 0) {
         rt_set_error("scene descriptor: non-positive film size / sample rate or negative count");
+        return RT_ERR_INVALID;
+    }
+    if ((s->n_spheres > 0 && (!s->spheres || !s->sphere_mat)) ||
+        (s->n_triangles > 0 && (!s->tri_verts || !s->tri_normals || !s->tri_mat || !s->tri_flags)) ||
+        (s->n_materials > 0 && !s->materials) || (s->n_lights > 0 && !s->lights)) {
+        rt_set_error("scene descriptor: a count is positive but its array is NULL");
         return RT_ERR_INVALID;
     }
     if (s->max_depth + 1 > RT_MAX_GEN) { rt_set_error("max_depth beyond the supported 63"); return RT_ERR_UNSUPPORTED; }
@@ -417,6 +426,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     tm.mark(3);
     rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1);
     tm.mark(3);
+    if (S.max_depth < 0) rtk_fill_background(st, S, c->P, nsamples, c->max_blocks);   // nothing is traced at all
     uint64_t bound = nsamples;
     for (int g = 0; g <= S.max_depth; g++) {
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
@@ -507,10 +517,20 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     const float4* tree_nodes[2] = {c->d_nodes, c->d_nodes_alt};
     const float4* tree_wide[2] = {c->d_wide, c->d_wide_alt};
     const int tree_depth[2] = {S.depth, c->depth_alt};
-    std::vector<hipEvent_t> ev((size_t)G * 4);
-    for (auto& e : ev) hipEventCreate(&e);
+    std::vector<hipEvent_t> ev((size_t)G * 4, nullptr);
     uint32_t* d_pick = nullptr;
-    static float te[2][5][RT_MAX_GEN + 1], tsh[2][5][RT_MAX_GEN + 1];
+    auto cleanup = [&]() {
+        for (auto& e : ev) if (e) hipEventDestroy(e);
+        hipFree(d_pick);
+        S.nodes = tree_nodes[0]; S.nodes4 = tree_wide[0]; S.depth = tree_depth[0]; S.root = 0;
+    };
+#define CAL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rt_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return (e_ == hipErrorOutOfMemory) ? RT_ERR_NOMEM : RT_ERR_HIP; } } while (0)
+    for (auto& e : ev) CAL_TRY(hipEventCreate(&e));
+    // [tree][walk mode][generation], milliseconds
+    struct Times { float v[2][5][RT_MAX_GEN + 1]; };
+    std::vector<Times> times(2);
+    auto& te = times[0].v;
+    auto& tsh = times[1].v;
     bool ok = false;
     // at most 32 Mi samples: enough to be in the throughput regime, and about one extra K3 frame in all
     uint32_t n = std::min(total, std::max(1u, std::min<uint32_t>(tiles_per_batch, (uint32_t)std::max<uint64_t>(1, (32ull << 20) / per_tile))));
@@ -518,8 +538,9 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         std::vector<uint32_t> pick(n);
         for (uint32_t k = 0; k < n; k++) pick[k] = c->tiles[(uint64_t)k * total / n];
         hipFree(d_pick); d_pick = nullptr;
-        HIP_TRY(hipMalloc(&d_pick, n * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpyAsync(d_pick, pick.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        CAL_TRY(hipMalloc(&d_pick, n * sizeof(uint32_t)));
+        CAL_TRY(hipMemcpyAsync(d_pick, pick.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        CAL_TRY(hipStreamSynchronize(c->stream));      // pick goes out of scope at the end of this round
         const uint32_t nsamples = (uint32_t)(n * per_tile);
         ok = true;
         for (int t = 0; t < ntrees && ok; t++) {
@@ -555,9 +576,8 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         }
         if (ok) break;
     }
-    S.nodes = tree_nodes[0]; S.nodes4 = tree_wide[0]; S.depth = tree_depth[0];
-    for (auto& e : ev) hipEventDestroy(e);
-    hipFree(d_pick);
+    cleanup();
+#undef CAL_TRY
     if (ok) {
         float best_total[2] = {0, 0};
         for (int t = 0; t < ntrees; t++)
@@ -610,6 +630,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         uint64_t v = strtoull(e, nullptr, 10);
         if (v > 0) want_samples = v;
     }
+    want_samples = std::min<uint64_t>(want_samples, 1ull << 30);      // sample indices of a batch are 32-bit
     uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
     if (per_tile > 0x7FFFFFFFull) { rt_set_error("sample_rate too large for one tile per batch"); return RT_ERR_UNSUPPORTED; }
     uint32_t total_tiles = (uint32_t)c->tiles.size();

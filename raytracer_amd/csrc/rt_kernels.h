@@ -17,6 +17,7 @@ void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks);
+void rtk_fill_background(hipStream_t st, const DScene& S, const DPool& P, uint32_t nsamples, int max_blocks);
 void rtk_finish(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles, uint32_t tile0,
                 uint32_t npixels, int shard_mode, uint8_t* out, float* outf, int max_blocks);
 void rtk_assemble(hipStream_t st, const uint8_t* all, size_t shard_bytes, int world, int width, int height,

@@ -1227,6 +1227,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounte
     }
 }
 
+// max_depth < 0: the primary ray itself sits past max_depth, so evaluateRayTree returns the
+// background for every sample without tracing anything (src/raytrace.cpp:132-135).
+__global__ void k_fill_background(DScene S, DPool P, uint32_t nsamples) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsamples; i += gridDim.x * blockDim.x)
+        P.scol[i] = make_float4(S.bg.x, S.bg.y, S.bg.z, 0.0f);
+}
+
 // ---------------------------------------------------------------- finish
 // ave (src/raytrace.cpp:1079-1089) then Pixel::SetClamp(c*255.0)
 // (src/raytrace.cpp:112, src/pixel.cpp:38-43): (int) truncation as x86-64
@@ -1408,6 +1415,10 @@ void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C) {
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks) {
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
+}
+void rtk_fill_background(hipStream_t st, const DScene& S, const DPool& P, uint32_t nsamples, int max_blocks) {
+    if (nsamples == 0) return;
+    hipLaunchKernelGGL(k_fill_background, dim3(grid_for(nsamples, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, nsamples);
 }
 void rtk_finish(hipStream_t st, const DCamera& cam, const DPool& P, const uint32_t* tiles, uint32_t tile0,
                 uint32_t npixels, int shard_mode, uint8_t* out, float* outf, int max_blocks) {

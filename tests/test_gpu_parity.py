@@ -271,6 +271,28 @@ def test_work_counters_are_optional_and_do_not_change_the_image(tracer):
     assert sum(st2.nodes_visited) == 0
 
 
+def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
+    # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
+    s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
+    tracer.load_scene(s)
+    rgb, rgbf, st = tracer.render(want_float=True)
+    orgb, orgbf, cnt, _ = oracle.render(s, threads=2)
+    assert np.array_equal(rgb, orgb) and np.array_equal(bits(rgbf), bits(orgbf))
+    assert st.rays_secondary == 0 and st.rays_shadow == 0 and st.generations == 0
+
+
+def test_descriptor_with_a_count_but_no_array_is_rejected():
+    import ctypes as C
+    from raytracer_amd import api
+    d, keep = load_scene("spheres1").desc()
+    d.spheres = None
+    with ra.Tracer() as t:
+        rc = t._lib.rt_load_scene(t._ctx, C.byref(d))
+        assert rc == api.RT_ERR_INVALID and b"NULL" in t._lib.rt_last_error()
+        with pytest.raises(ra.RtError):          # the failed load left no scene behind
+            t.render()
+
+
 def test_edge_cases(tracer):
     # empty scene: background everywhere, no secondary or shadow rays
     s = ra.SceneArrays(width=70, height=33, background=np.array([.25, .5, 1], np.float32))
