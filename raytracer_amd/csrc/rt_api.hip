@@ -531,6 +531,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     std::vector<Times> times(2);
     auto& te = times[0].v;
     auto& tsh = times[1].v;
+    uint32_t sample_rays[RT_MAX_GEN + 1] = {0};      // rays per generation of the sample (for the verbose line)
     bool ok = false;
     // at most 32 Mi samples: enough to be in the throughput regime, and about one extra K3 frame in all
     uint32_t n = std::min(total, std::max(1u, std::min<uint32_t>(tiles_per_batch, (uint32_t)std::max<uint64_t>(1, (32ull << 20) / per_tile))));
@@ -569,6 +570,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                     hipStreamSynchronize(st) != hipSuccess) { ok = false; n = 0; break; }
                 if (hc.overflow) { ok = false; break; }      // sample does not fit the pool: halve it
                 for (int g = 0; g < G; g++) {
+                    sample_rays[g] = hc.gen_count[g];
                     hipEventElapsedTime(&te[t][mode][g], ev[4 * g + 0], ev[4 * g + 1]);
                     hipEventElapsedTime(&tsh[t][mode][g], ev[4 * g + 2], ev[4 * g + 3]);
                 }
@@ -601,6 +603,8 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
             const char* tag = "?-LPW";
             fprintf(stderr, " -> %s; extend (lane/packet/wide ms):", t ? "PLOC" : "Karras");
             for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, te[t][2][g], te[t][3][g], te[t][4][g] > 1e29f ? 0.0f : te[t][4][g], tag[c->mode_extend[g]]);
+            fprintf(stderr, "; rays:");
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %u", g, sample_rays[g]);
             fprintf(stderr, "; shadow:");
             for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, tsh[t][2][g], tsh[t][3][g], tsh[t][4][g] > 1e29f ? 0.0f : tsh[t][4][g], tag[c->mode_shadow[g]]);
             fprintf(stderr, "\n");

@@ -69,20 +69,31 @@ __device__ __forceinline__ uint32_t wq_grab(uint32_t* counter, uint32_t lane) {
 template <class F>
 __device__ __forceinline__ void for_each_group(uint32_t* wq, uint64_t ngroups, F&& body) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    // Fewer groups than waves (the thin late generations): one group per wave, no queue.  With the
+    // queue a wave draws its second group before it starts the first, so half of the waves would
+    // walk two groups back to back while the other half found the queues empty and left.
+    const bool one_each = ngroups <= (uint64_t)((gridDim.x * blockDim.x) >> 6);
+    if (one_each && wave >= ngroups) return;
     uint32_t q = wave % RT_NQ;
     int probes = 0;
-    uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
+    uint32_t k = 0;
+    if (!one_each) k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
     while (true) {
-        uint64_t grp = (uint64_t)k * RT_NQ + q;
-        if (grp >= ngroups) {
-            if (++probes > RT_WQ_PROBES) break;
-            q = (q + 1) % RT_NQ;
-            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
-            continue;
+        uint64_t grp = wave;
+        uint32_t kn = 0;
+        if (!one_each) {
+            grp = (uint64_t)k * RT_NQ + q;
+            if (grp >= ngroups) {
+                if (++probes > RT_WQ_PROBES) break;
+                q = (q + 1) % RT_NQ;
+                k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
+                continue;
+            }
+            kn = wq_grab(wq + q * RT_WQ_STRIDE, lane);          // next group, in flight during body()
         }
-        uint32_t kn = wq_grab(wq + q * RT_WQ_STRIDE, lane);     // next group, in flight during body()
         body(grp);
+        if (one_each) break;
         k = (uint32_t)__builtin_amdgcn_readfirstlane((int)kn);
     }
 }

@@ -1,4 +1,16 @@
-mkdir -p gpurun_out
-export RT_VERBOSE=1 RT_STAGE_TIMES=1
-timeout -k 10 280 python -u bench.py --workload k3 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/exp.json 2> gpurun_out/exp.err || { tail -5 gpurun_out/exp.err; exit 1; }
-grep -v amdgpu.ids gpurun_out/exp.err | cut -c1-400 | tail -60
+out=$GRAFT_REPO_ROOT/gpurun_out/w8pmc; rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+export RT_PACKET_GENS=9 RT_PACKET_SHADOW_GENS=9
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out -o k -- python3 $GRAFT_REPO_ROOT/tools/_w8.py 8 > $out/log.txt 2>&1 || { tail $out/log.txt; exit 1; }
+cd $GRAFT_REPO_ROOT; python3 - <<'PY'
+import csv, glob
+from collections import defaultdict
+f = glob.glob('gpurun_out/w8pmc/**/*counter_collection.csv', recursive=True)[0]
+d = defaultdict(dict)
+for r in csv.DictReader(open(f)):
+    if 'k_extend' in r['Kernel_Name'] or 'k_shadow' in r['Kernel_Name']:
+        key = (int(r['Dispatch_Id']), r['Kernel_Name'][5:20])
+        d[key][r['Counter_Name']] = float(r['Counter_Value']); d[key]['us'] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+for k in sorted(d)[-12:]:
+    v = d[k]
+    print(k, {n: round(x, 1) for n, x in v.items()})
+PY

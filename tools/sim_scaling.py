@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-GPU share of the K3 frame at world sizes 1, 2, 4, 8, rendered on ONE GPU: rank 0's shard
+of each world size, timed on its own.  The ideal time at world size N is t(1)/N; what is above it
+is what the split itself costs (thin late generations, launch floors) before any gather.
+8-GPU runs are the driver's to launch; this measures the per-GPU work only.
+
+usage: sim_scaling.py [frames]      (RT_VERBOSE=1 adds the per-generation calibration timings)"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RT_STAGE_TIMES", "1")
+import torch  # noqa: E402  (before the tracer library, see tests/conftest.py)
+import raytracer_amd as ra  # noqa: E402
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    here = os.path.dirname(os.path.abspath(__file__))
+    scene = ra.SceneArrays.load(os.path.join(here, "..", "tests", "golden", "scenes", "dragon.npz"))
+    scene = scene.copy(width=3840, height=2160, spp=16, seed=1)
+    base = None
+    for world in (1, 2, 4, 8):
+        t = ra.Tracer(device=0)
+        t.load_scene(scene)
+        buf = torch.empty(ra.shard_bytes(scene.width, scene.height, world), dtype=torch.uint8, device="cuda:0")
+        t.render_shard(0, world, buf.data_ptr())          # calibration + pool growth
+        t.render_shard(0, world, buf.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            st = t.render_shard(0, world, buf.data_ptr())
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / frames * 1e3
+        base = base or ms
+        print(json.dumps({"world": world, "ms_per_frame": round(ms, 3), "ideal_ms": round(base / world, 3),
+                          "efficiency": round(base / world / ms, 3), "rays": st.rays,
+                          "stage_ms": {k: round(getattr(st, "ms_" + k), 3) for k in ("extend", "shadow", "shade", "other")}}))
+        t.close()
+
+
+if __name__ == "__main__":
+    main()
