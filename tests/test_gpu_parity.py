@@ -271,6 +271,33 @@ def test_work_counters_are_optional_and_do_not_change_the_image(tracer):
     assert sum(st2.nodes_visited) == 0
 
 
+def test_k3_full_size_frame_against_oracle_crops_and_across_partitions(oracle):
+    """The bench configuration itself (dragon, 3840x2160, 16 spp, depth 5).  The oracle is brute force
+    on the CPU and cannot render 133 M samples, so it renders crops of the full-resolution frame
+    (same film, same sample indices) where the image is busiest and where it is empty; the size-
+    independent properties cover the rest: the ray counts of the frame, and a frame put together
+    from two GPUs' shards is byte-identical to the one rendered whole."""
+    import torch
+    scene = load_scene("dragon").copy(width=3840, height=2160, spp=16, seed=1)
+    with ra.Tracer() as t:
+        t.load_scene(scene)
+        rgb, rgbf, st = t.render(want_float=True)
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (132710400, 109577458, 110625041)
+        for roi in [(1900, 1000, 1932, 1024), (2400, 1300, 2432, 1324), (1300, 700, 1332, 716), (0, 0, 16, 8), (3828, 2150, 3840, 2160)]:
+            orgb, orgbf, _, _ = oracle.render(scene, roi=roi, threads=16)
+            check_image(crop(rgb, roi), crop(rgbf, roi), orgb, orgbf, f"K3 full size, crop {roi}")
+        world = 2
+        nbytes = ra.shard_bytes(scene.width, scene.height, world)
+        shards = torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda:0")
+        whole = torch.empty(scene.height * scene.width * 3, dtype=torch.uint8, device="cuda:0")
+        total = 0
+        for rank in range(world):
+            total += t.render_shard(rank, world, shards.data_ptr() + rank * nbytes).rays
+        t.assemble_shards(shards.data_ptr(), world, whole.data_ptr())
+        assert total == st.rays
+        assert np.array_equal(whole.cpu().numpy().reshape(scene.height, scene.width, 3), rgb)
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
