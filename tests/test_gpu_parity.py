@@ -298,6 +298,32 @@ def test_k3_full_size_frame_against_oracle_crops_and_across_partitions(oracle):
         assert np.array_equal(whole.cpu().numpy().reshape(scene.height, scene.width, 3), rgb)
 
 
+def test_k5_full_scene_and_film_against_oracle_crops(oracle):
+    """The synthetic scene at full scale (10^6 spheres + 10^7 triangles) on the full 7680x4320 film.
+    The oracle tests every primitive for every ray (half a second per ray), so it renders two 4x4
+    crops at 2 samples per pixel; the GPU renders the shard (1 of 16) that holds each crop's tile."""
+    import torch
+    from raytracer_amd import dist as rd
+    from raytracer_amd.synth import synthetic_scene
+    scene = synthetic_scene(scale=1.0).copy(spp=2)
+    assert (scene.width, scene.height, len(scene.spheres), len(scene.tri_verts)) == (7680, 4320, 1000000, 10000000)
+    world = 16
+    with ra.Tracer() as t:
+        t.load_scene(scene)
+        buf = torch.zeros(ra.shard_bytes(scene.width, scene.height, world), dtype=torch.uint8, device="cuda:0")
+        for x0, y0 in [(3840, 2160), (3012, 1796)]:
+            tx, ty = x0 // ra.RT_TILE, y0 // ra.RT_TILE
+            rank = next(r for r in range(world) if (tx, ty) in rd.tile_list(scene.width, scene.height, r, world))
+            st = t.render_shard(rank, world, buf.data_ptr())
+            assert st.accel_used == ra.RT_ACCEL_LBVH and st.rays_shadow > 0
+            k = rd.tile_list(scene.width, scene.height, rank, world).index((tx, ty))
+            tile = buf.cpu().numpy()[k * ra.RT_TILE * ra.RT_TILE * 3:(k + 1) * ra.RT_TILE * ra.RT_TILE * 3].reshape(ra.RT_TILE, ra.RT_TILE, 3)
+            px, py = x0 % ra.RT_TILE, y0 % ra.RT_TILE
+            orgb, _, cnt, _ = oracle.render(scene, roi=(x0, y0, x0 + 4, y0 + 4), threads=16)
+            assert cnt.shadow > 0, "the crop was meant to see geometry"
+            assert np.array_equal(tile[py:py + 4, px:px + 4], orgb), (x0, y0)
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
