@@ -593,7 +593,11 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         }
         adopt_tree(c, t == 1);
         for (int g = 0; g < G; g++) {
-            auto best_of = [](float lane, float packet, float wide) { return (packet <= lane && packet <= wide) ? 3 : (wide < lane ? 4 : 2); };
+            // within 10 % the packet walk is kept: thin generations time within noise of each other, and a
+            // choice that flips from run to run would make the work counters (fetches per ray) flip with it
+            auto best_of = [](float lane, float packet, float wide) {
+                return (packet <= 1.1f * lane && packet <= 1.1f * wide) ? 3 : (wide < lane ? 4 : 2);
+            };
             c->mode_extend[g] = (int8_t)best_of(te[t][2][g], te[t][3][g], te[t][4][g]);
             c->mode_shadow[g] = (int8_t)best_of(tsh[t][2][g], tsh[t][3][g], tsh[t][4][g]);
         }

@@ -7,6 +7,8 @@ Reads <dir>/*_trace/**/_kernel_stats.csv (kernel-trace --stats) and every
 <dir>/*/**/_counter_collection.csv (one --pmc pass each) and writes
   <prefix>_kernel_stats.csv   per-kernel calls / total / average duration (our kernels only)
   <prefix>_pmc.json           per kernel and counter: sum over dispatches and mean per dispatch
+  <prefix>_timed_launches.json  average duration of the traversal launches of the timed frames only
+  <prefix>_bench.json         (with a workload argument) the run's bench line, traffic filled from its own passes
 FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE reads half
 of a wide coalesced stream, so `hbm_read_bytes_corrected` doubles it (upper bound for
 narrow accesses)."""
@@ -63,25 +65,57 @@ def main():
         if "SQ_ACTIVE_INST_VALU" in cs and "SQ_BUSY_CYCLES" in cs:
             res[k]["valu_active_per_wave_cycle"] = cs["SQ_ACTIVE_INST_VALU"][0] / max(1.0, cs["SQ_WAVE_CYCLES"][0])
     json.dump(res, open(prefix + "_pmc.json", "w"), indent=1, sort_keys=True)
+    # The traversal kernels of the TIMED frames only.  A run also holds the calibration launches (a
+    # quarter-size sample, every walk of both trees) and the counting frame (<.., true> variants), so
+    # the plain per-kernel averages above mix launch sizes; these do not.
+    gens, steps = 6, 5
+    bj = os.path.join(src, "bench.json")
+    if os.path.exists(bj):
+        b = json.load(open(bj))
+        gens, steps = int(b["config"]["max_depth"]) + 1, int(b["steps"])
+
+    def traversal_rows(path, base):
+        rows = [r for r in csv.DictReader(open(path))
+                if re.search(r"\b" + base + r"<\d+, false>", r["Kernel_Name"])]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        return rows
+
+    timed = {}
+    for f in glob.glob(os.path.join(src, "*trace*", "**", "*_kernel_trace.csv"), recursive=True):
+        for base in ("k_extend", "k_shadow"):
+            rows = traversal_rows(f, base)[-gens * steps:]
+            if rows:
+                us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+                timed[base] = {"launches": len(us), "avg_us": round(sum(us) / len(us), 2),
+                               "min_us": round(min(us), 2), "max_us": round(max(us), 2)}
     if len(sys.argv) > 3:
-        # HBM bytes per launch of the traversal kernels (the variant launched most), for bench.py's
-        # roofline.traffic: corrected FETCH_SIZE (x2, an upper bound for narrow accesses) + WRITE_SIZE
-        tpath = os.path.join(os.path.dirname(prefix) or ".", "hbm_traffic.json")
-        table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        # HBM bytes per launch for bench.py's roofline.traffic: corrected FETCH_SIZE (x2, an upper bound
+        # for narrow accesses) + WRITE_SIZE, averaged over the launches of the LAST frame of each pass
         entry = {}
         for base in ("k_extend", "k_shadow"):
-            cands = [(v["FETCH_SIZE"]["dispatches"], k) for k, v in res.items()
-                     if k.startswith(base) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
-            if cands:
-                k = max(cands)[1]
-                entry[base] = round(res[k]["hbm_read_bytes_corrected"]["mean_per_dispatch"] +
-                                    res[k]["hbm_write_bytes"]["mean_per_dispatch"])
-                entry[base + "_variant"] = k
+            total = 0.0
+            for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+                for f in glob.glob(os.path.join(src, "*", "**", "*_counter_collection.csv"), recursive=True):
+                    rows = [r for r in traversal_rows(f, base) if r["Counter_Name"] == counter][-gens:]
+                    if rows:
+                        total += scale * sum(float(r["Counter_Value"]) for r in rows) / len(rows)
+                        entry[base + "_launches_averaged"] = len(rows)
+            if total:
+                entry[base] = round(total)
+        tpath = os.path.join(os.path.dirname(prefix) or ".", "hbm_traffic.json")
+        table = json.load(open(tpath)) if os.path.exists(tpath) else {}
         table[sys.argv[3]] = entry
         json.dump(table, open(tpath, "w"), indent=1, sort_keys=True)
+        if os.path.exists(bj):
+            # the bench line of this profile run, with the traffic its own counter passes measured
+            b = json.load(open(bj))
+            if "k_extend" in entry:
+                b["roofline"]["traffic"] = entry["k_extend"]
+            b["roofline"]["rocprofv3_kernel_trace"] = timed
+            json.dump(b, open(prefix + "_bench.json", "w"))
+    json.dump(timed, open(prefix + "_timed_launches.json", "w"), indent=1, sort_keys=True)
     print(open(prefix + "_kernel_stats.csv").read() if os.path.exists(prefix + "_kernel_stats.csv") else "")
-    print(json.dumps({k: {c: (round(v["mean_per_dispatch"], 1) if isinstance(v, dict) else round(v, 4)) for c, v in cs.items()}
-                      for k, cs in res.items()}, indent=1))
+    print(json.dumps(timed))
 
 
 if __name__ == "__main__":
