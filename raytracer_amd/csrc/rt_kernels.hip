@@ -1259,10 +1259,11 @@ __device__ __forceinline__ uint8_t quantise(float c) {
 
 // One pixel per thread, but a pixel's samples lie 16 * spp bytes apart from its
 // neighbour's: read per thread, every load touches 64 cache lines.  The block therefore
-// stages its 256 pixels through LDS, 16 samples at a time: coalesced loads (lane l takes
+// stages its 256 pixels through LDS, 8 samples at a time (25 KB: six blocks per CU; 16 at a time
+// leaves three and is 19 % slower): coalesced loads (lane l takes
 // record l of the block's contiguous run), then each thread adds up its own pixel in
-// sample order.  49 floats per pixel row keeps the per-thread reads off each other's banks.
-#define FIN_CHUNK 16
+// sample order.  25 floats per pixel row keeps the per-thread reads off each other's banks.
+#define FIN_CHUNK 8
 #define FIN_ROW (3 * FIN_CHUNK + 1)
 __global__ __launch_bounds__(RT_BLOCK) void k_finish(DCamera cam, DPool P, const uint32_t* tiles,
                                                      uint32_t tile0, uint32_t npixels, int shard_mode,
