@@ -20,15 +20,17 @@
 #include "rt_kernels.h"
 #include "rt_packet_asm.h"
 
-// k_shade: the compiler settles for 3 waves per SIMD (150 VGPRs) although 128 registers cost it nothing;
-// the kernel is latency-bound, so the fourth wave is free speed.
+// k_shade: the compiler settles for 3 waves per SIMD (150 VGPRs); capped at 128 registers it spills about
+// twenty dwords, and the kernel waits on memory most of the time, so the fourth wave more than pays for them
+// (a fifth does not: measured).
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
 #ifdef RT_WAVES
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES)))
 #else
-// the per-lane walks hide memory latency with waves: 5 per SIMD at the price of a few spilled dwords
+// the per-lane walks hide memory latency with waves: 5 per SIMD at the price of a few spilled dwords;
+// the packet walks fit 6 without spilling
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : (ACCEL == 3 ? RT_PACKET_WAVES : 1), 8)))
 #endif
 #ifndef RT_LANE_WAVES
