@@ -65,6 +65,7 @@ struct rt_ctx {
     bool tuned = false, forced_modes = false;
     uint32_t tiles_cap = 0;    // batches of this scene that overflowed a pool that could not grow were split: keep to that size
     bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
+    bool two_children = false; // some material can send out a reflection AND a refraction ray: resolve passes needed
     DScene S{};
     DCamera cam{};
     float4* d_sph = nullptr; int* d_sph_mat = nullptr;
@@ -256,6 +257,14 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
         mats[4 * (size_t)i + 2] = make_float4(m[6], m[7], m[8], 0.0f);     // specular
         mats[4 * (size_t)i + 3] = make_float4(m[10], m[11], m[12], 0.0f);  // transmissive
     }
+    // A hit spawns a reflection ray iff every specular component is non-zero and a refraction ray iff
+    // every transmissive one is (src/raytrace.cpp:589, :600): only a material with both can give a ray
+    // two children, and only such rays need the bottom-up resolve passes.
+    c->two_children = false;
+    for (int i = 0; i < s->n_materials; i++) {
+        const float* m = s->materials + 14 * (size_t)i;
+        if (m[6] != 0 && m[7] != 0 && m[8] != 0 && m[10] != 0 && m[11] != 0 && m[12] != 0) c->two_children = true;
+    }
     std::vector<DLight> lights(s->n_lights);
     for (int i = 0; i < s->n_lights; i++) {
         const rt_light& L = s->lights[i];
@@ -444,7 +453,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         tm.mark(2);
         bound = std::min<uint64_t>(bound * 2, cap);
     }
-    for (int g = S.max_depth - 1; g >= 0; g--)
+    for (int g = S.max_depth - 1; g >= 0 && c->two_children; g--)
         rtk_resolve(st, S, c->P, c->d_counters, g, std::min<uint64_t>((uint64_t)nsamples << std::min(g, 20), cap), c->max_blocks);
     rtk_finish(st, c->cam, c->P, c->d_tiles, tile0, npixels, shard_mode, d_out, d_outf, c->max_blocks);
     if (c->count_work) rtk_reduce_stats(st, c->P, c->d_counters);

@@ -100,11 +100,42 @@ __device__ __forceinline__ void for_each_group(uint32_t* wq, uint64_t ngroups, F
     }
 }
 
-__device__ __forceinline__ void deliver(const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c) {
-    float4 v = make_float4(c.x, c.y, c.z, 0.0f);
-    if (g == 0) P.scol[parent] = v;
-    else if (slot == 0) P.cre[parent] = v;
-    else P.cra[parent] = v;
+// A ray of generation g whose colour is final hands it to its parent (`parent` = the parent's pool
+// index, or the sample index for g == 0; `slot` = 0 for a reflection ray, 1 for a refraction ray).
+// A parent with ONE child is finished by that very colour: local + spec (or trans) * child, the
+// reference's own operation (src/raytrace.cpp:594-596, :625-627), so the walk goes on to the
+// grandparent, and so on up to the sample.  A parent with TWO children needs both colours, added
+// in a fixed order: the child parks its colour in the parent's cre / cra slot and k_resolve
+// finishes that parent later.  The parent's record (`loc`: local colour + material and spawn
+// bits) was written by the shade launch of the generation before.
+// `l` = the parent's loc record when the caller has fetched it already (g > 0), see deliver below.
+__device__ __forceinline__ void deliver_from(const DScene& S, const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c, float4 l) {
+    while (g > 0) {
+        const uint32_t code = fbits(l.w);
+        if ((code & 3u) == 3u) {
+            const float4 v = make_float4(c.x, c.y, c.z, 0.0f);
+            if (slot == 0) P.cre[parent] = v;
+            else P.cra[parent] = v;
+            return;
+        }
+        const float4 k = S.mats[4 * (size_t)(code >> 2) + 2 + slot];     // specular for slot 0, transmissive for slot 1
+        float rval = l.x, gval = l.y, bval = l.z;
+        rval += k.x * c.x; gval += k.y * c.y; bval += k.z * c.z;
+        c = f3(rval, gval, bval);
+        g--;
+        if (g > 0) {
+            const uint32_t link = P.link[parent];
+            parent = link & 0x7FFFFFFFu;
+            slot = link >> 31;
+            l = P.loc[parent];
+        }
+    }
+    P.scol[parent] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+__device__ __forceinline__ void deliver(const DScene& S, const DPool& P, int g, uint32_t parent, uint32_t slot, F3 c) {
+    float4 l = make_float4(0, 0, 0, 0);
+    if (g > 0) l = P.loc[parent];
+    deliver_from(S, P, g, parent, slot, c, l);
 }
 
 // ---------------------------------------------------------------- brute force (LDS staged)
@@ -705,6 +736,11 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
     trace<ACCEL, false>(S, lds, active, o, d, __builtin_inff(), best, best_d2, uv, ts);
     bool hit = active && best >= 0;
     bool refl = false, refr = false;
+    // a miss returns the background to the parent: its record is asked for now, so that the fetch
+    // travels while the hit lanes of the wave build their records
+    const bool miss = active && !hit;
+    float4 ploc = make_float4(0, 0, 0, 0);
+    if (miss && g > 0) ploc = P.loc[R.parent];
     if (hit) {
         F3 point, normal; int mat;
         make_hit_uv(S, o, d, best, uv, point, normal, mat);
@@ -716,9 +752,8 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
             Spawn sp = spawn_of(f3(M[2]), f3(M[3]), M[1].w, d, normal);
             refl = sp.refl; refr = sp.refr;
         }
-    } else if (inrange) {
-        if (active) deliver(P, g, R.parent, R.slot, S.bg);
     }
+    if (miss) deliver_from(S, P, g, R.parent, R.slot, S.bg, ploc);
     unsigned long long mh = __ballot(hit), m1 = __ballot(refl), m2 = __ballot(refr);
     if ((threadIdx.x & 63) == 0 && inrange) {
         uint32_t grp = gbase + (i >> 6);
@@ -818,7 +853,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
                         bits |= (spn.refl ? 2u : 0u) | (spn.refr ? 4u : 0u);
                     }
                 } else {
-                    if (valid) deliver(P, g, parent, slot, S.bg);
+                    if (valid) deliver(S, P, g, parent, slot, S.bg);
                 }
                 flags[k] = (uint8_t)bits;
                 state = IDLE;
@@ -1184,7 +1219,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
             leaf = true;
         }
         if (leaf) {
-            deliver(P, g, parent, slot, f3(rval, gval, bval));
+            deliver(S, P, g, parent, slot, f3(rval, gval, bval));
             continue;
         }
         uint32_t code = ((uint32_t)mat << 2) | (sp.refl ? 1u : 0u) | (sp.refr ? 2u : 0u);
@@ -1213,36 +1248,31 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
 }
 
 // ---------------------------------------------------------------- resolve (bottom-up)
-// Adds the children's colours in the reference's order -- reflection first
-// (src/raytrace.cpp:594-596), then refraction (:625-627) -- and returns the sum
-// to the parent.
+// Rays that sent out BOTH a reflection and a refraction ray: adds the children's colours in the
+// reference's order -- reflection first (src/raytrace.cpp:594-596), then refraction (:625-627) --
+// and hands the sum on (deliver).  Launched per generation, deepest first, and only for scenes
+// that have a material which can spawn both.
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DScene S, DPool P, DCounters* C, int g) {
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
     const uint32_t gbase = C->gbase[g];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        // only rays that spawned children have anything pending: the spawn ballots say which
         const uint32_t grp = gbase + (i >> 6);
-        const unsigned long long pending = P.mask_refl[grp] | P.mask_refr[grp];
-        if (!((pending >> (i & 63u)) & 1ull)) continue;
+        const unsigned long long both = P.mask_refl[grp] & P.mask_refr[grp];
+        if (!((both >> (i & 63u)) & 1ull)) continue;
         uint32_t r = start + i;
         float4 l = P.loc[r];
-        uint32_t code = fbits(l.w);
-        const float4* M = S.mats + 4 * (size_t)(code >> 2);
+        const float4* M = S.mats + 4 * (size_t)(fbits(l.w) >> 2);
         float rval = l.x, gval = l.y, bval = l.z;
-        if (code & 1u) {
-            float4 s = M[2], c = P.cre[r];
-            rval += s.x * c.x; gval += s.y * c.y; bval += s.z * c.z;
-        }
-        if (code & 2u) {
-            float4 t = M[3], c = P.cra[r];
-            rval += t.x * c.x; gval += t.y * c.y; bval += t.z * c.z;
-        }
-        if (g == 0) deliver(P, 0, r, 0, f3(rval, gval, bval));
+        float4 s = M[2], c = P.cre[r];
+        rval += s.x * c.x; gval += s.y * c.y; bval += s.z * c.z;
+        float4 t = M[3], ca = P.cra[r];
+        rval += t.x * ca.x; gval += t.y * ca.y; bval += t.z * ca.z;
+        if (g == 0) deliver(S, P, 0, r, 0, f3(rval, gval, bval));
         else {
             const uint32_t link = P.link[r];
-            deliver(P, g, link & 0x7FFFFFFFu, link >> 31, f3(rval, gval, bval));
+            deliver(S, P, g, link & 0x7FFFFFFFu, link >> 31, f3(rval, gval, bval));
         }
     }
 }
