@@ -324,6 +324,89 @@ def test_k5_full_scene_and_film_against_oracle_crops(oracle):
             assert np.array_equal(tile[py:py + 4, px:px + 4], orgb), (x0, y0)
 
 
+def test_coincident_primitives_and_tie_rules(oracle, monkeypatch):
+    """Thousands of primitives at the same place: every box overlaps every other (the second hierarchy
+    degenerates and is rejected), and every ray meets many primitives at exactly the same distance, where
+    the reference keeps the lowest index of a list and prefers a sphere to an equally distant triangle
+    (src/raytrace.cpp:172, :250, :361).  Each copy has its own material, so a wrong winner changes the colour."""
+    rng = np.random.default_rng(3)
+    n = 1500
+    mats = np.zeros((2 * n, 14), np.float32)
+    mats[:, 0:3] = rng.random((2 * n, 3)); mats[:, 3:6] = rng.random((2 * n, 3)); mats[:, 9] = 5; mats[:, 13] = 1
+    mats[::7, 6:9] = 0.5                                    # some mirrors among them
+    tri = np.tile(np.array([[-2, -1, 6, 2, -1, 6, 0, 2.5, 6]], np.float32), (n, 1))
+    nrm = np.tile(np.array([[0, 0, -1] * 3], np.float32), (n, 1))
+    sph = np.tile(np.array([[0.8, 0.3, 5.5, 0.9]], np.float32), (n, 1))
+    sph[n // 2:, 0] = -1.0                                   # two piles of spheres, one pile of triangles
+    lights = np.array([[2, 40, 40, 40, 3, 4, 0, 0, 0, 0, 0, 0], [1, .5, .5, .5, 0, 0, 0, .2, -1, .3, 0, 0]], np.float32)
+    scene = ra.SceneArrays(width=96, height=72, spp=2, seed=5, spheres=sph, sphere_mat=np.arange(n, dtype=np.int32),
+                           tri_verts=tri, tri_normals=nrm, tri_flags=np.zeros(n, np.int32),
+                           tri_mat=np.arange(n, 2 * n, dtype=np.int32), materials=mats, lights=lights,
+                           ambient=np.array([.1, .1, .1], np.float32), background=np.array([.2, .3, .4], np.float32))
+    orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
+    images = {}
+    for label, env in [("brute", None), ("packet", {"RT_PACKET_GENS": "64", "RT_PACKET_SHADOW_GENS": "64"}),
+                       ("lane", {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0"}), ("calibrated", {})]:
+        for k in ("RT_PACKET_GENS", "RT_PACKET_SHADOW_GENS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        with ra.Tracer(accel=ra.RT_ACCEL_BRUTE if env is None else ra.RT_ACCEL_LBVH) as t:
+            t.load_scene(scene)
+            rgb, rgbf, st = t.render(want_float=True)
+        check_image(rgb, rgbf, orgb, orgbf, f"coincident primitives, {label}")
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow), label
+
+
+def _deep_scene(ties=2048):
+    # Morton keys 0 (a pile of `ties` coincident spheres), 1, 2, 4, ... 2^62 (one tiny sphere each) and the
+    # far corner: the hierarchy is a chain of 63 levels with the pile's index tie-break levels below it
+    pts = [(0.0, 0.0, 0.0)] * ties
+    for j in range(21):
+        v = float(2.0 ** j) / float(2 ** 21)
+        pts += [(v, 0, 0), (0, v, 0), (0, 0, v)]
+    pts.append((1.0, 1.0, 1.0))
+    pts = np.array(pts, np.float32) * 8.0
+    n = len(pts)
+    sph = np.concatenate([pts, np.full((n, 1), 1e-7, np.float32)], 1)
+    sph[:ties, 3] = 0.6
+    sph[-1, 3] = 0.8
+    mats = np.zeros((n, 14), np.float32)
+    mats[:, 0:3] = np.random.default_rng(1).random((n, 3)); mats[:, 3:6] = 0.5; mats[:, 6:9] = 0.3; mats[:, 9] = 5; mats[:, 13] = 1
+    return ra.SceneArrays(width=80, height=60, spp=2, seed=9, spheres=sph, sphere_mat=np.arange(n, dtype=np.int32),
+                          materials=mats, cam_pos=np.array([0.5, 0.4, -2.5], np.float32),
+                          ambient=np.array([.3, .3, .3], np.float32), background=np.array([.1, .2, .3], np.float32),
+                          lights=np.array([[2, 30, 30, 30, 1, 2, -3, 0, 0, 0, 0, 0]], np.float32))
+
+
+def test_hierarchy_deeper_than_64_levels(oracle, monkeypatch):
+    """A tree deeper than 64 takes the fall-backs: the packet walk leaves its one-register stack for the
+    128-entry one, no 4-wide collapse exists.  Every walk must still agree with brute force and the oracle."""
+    scene = _deep_scene()
+    orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
+    assert cnt.secondary > 0 and cnt.shadow > 0
+    rng = np.random.default_rng(11)
+    o, d = _random_rays(scene, 4096, rng)
+    for label, env in [("brute", None), ("packet", {"RT_PACKET_GENS": "64", "RT_PACKET_SHADOW_GENS": "64"}),
+                       ("lane", {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0"}), ("calibrated", {})]:
+        for k in ("RT_PACKET_GENS", "RT_PACKET_SHADOW_GENS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        with ra.Tracer(accel=ra.RT_ACCEL_BRUTE if env is None else ra.RT_ACCEL_LBVH) as t:
+            t.load_scene(scene)
+            if label == "calibrated":
+                ref_prim, ref_d2 = t.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
+                for accel in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET):
+                    prim, d2 = t.query_rays(o, d, accel=accel)
+                    assert np.array_equal(prim, ref_prim) and np.array_equal(bits(d2[prim >= 0]), bits(ref_d2[ref_prim >= 0]))
+                with pytest.raises(ra.RtError):                  # no 4-wide collapse of a tree this deep
+                    t.query_rays(o, d, accel=ra.RT_ACCEL_LBVH_WIDE)
+            rgb, rgbf, st = t.render(want_float=True)
+        check_image(rgb, rgbf, orgb, orgbf, f"deep hierarchy, {label}")
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow), label
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
