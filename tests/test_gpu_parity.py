@@ -407,6 +407,36 @@ def test_hierarchy_deeper_than_64_levels(oracle, monkeypatch):
         assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow), label
 
 
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 1), (37, 19, 3), (5, 70, 64)])
+def test_many_lights_degenerate_triangles_and_odd_films(oracle, tracer, w, h, spp):
+    """Nine lights of every kind (one work item per hit and light in the shadow kernel), triangles of zero
+    area (detA == 0: the literal division path of the triangle test, NaN comparisons as the reference makes
+    them), a film that is not a multiple of the 32x32 tile, and more samples per pixel than pixels."""
+    base = load_scene("test_reasonable")
+    rng = np.random.default_rng(21)
+    lights = []
+    for k in range(9):
+        kind = 1 + k % 3                                      # directional, point, spot
+        col = rng.uniform(2, 30, 3) if kind != 1 else rng.uniform(0.1, 0.6, 3)
+        pos = rng.uniform(-6, 6, 3); dr = rng.normal(size=3)
+        lights.append([kind, *col, *pos, *dr, 20 + 5 * k, 50 + 3 * k])
+    tv = base.tri_verts.copy(); tn = base.tri_normals.copy(); tf = base.tri_flags.copy(); tm = base.tri_mat.copy()
+    if len(tv) == 0:
+        tv = np.zeros((0, 9), np.float32); tn = np.zeros((0, 9), np.float32)
+    degenerate = np.array([[0, 0, 4, 0, 0, 4, 1, 1, 4], [1, 0, 3, 2, 0, 3, 3, 0, 3], [0, 0, 5, 0, 0, 5, 0, 0, 5]], np.float32)
+    tv = np.concatenate([tv, degenerate]); tn = np.concatenate([tn, np.tile([[0, 0, -1] * 3], (3, 1)).astype(np.float32)])
+    tf = np.concatenate([tf, np.array([0, 1, 0], np.int32)]); tm = np.concatenate([tm, np.zeros(3, np.int32)])
+    scene = base.copy(width=w, height=h, spp=spp, seed=4, lights=np.array(lights, np.float32),
+                      tri_verts=tv, tri_normals=tn, tri_flags=tf, tri_mat=tm)
+    orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
+    for accel in (ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH):
+        with ra.Tracer(accel=accel) as t:
+            t.load_scene(scene)
+            rgb, rgbf, st = t.render(want_float=True)
+        check_image(rgb, rgbf, orgb, orgbf, f"{w}x{h}x{spp} accel {accel}")
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow)
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
