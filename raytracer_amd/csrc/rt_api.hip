@@ -556,8 +556,10 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         for (int t = 0; t < ntrees && ok; t++) {
             S.nodes = tree_nodes[t]; S.nodes4 = tree_wide[t]; S.depth = tree_depth[t]; S.root = 0;
             for (int mode = 2; mode <= 4 && ok; mode++) {
-                if (mode == 4 && !tree_wide[t]) {
-                    for (int g = 0; g < G; g++) te[t][4][g] = tsh[t][4][g] = 1e30f;
+                // the per-lane walk on the binary tree is timed only where no 4-wide collapse exists: wherever
+                // both were timed the 4-wide one won, and the binary one is the most expensive trial of all
+                if ((mode == 4 && !tree_wide[t]) || (mode == 2 && tree_wide[t])) {
+                    for (int g = 0; g < G; g++) te[t][mode][g] = tsh[t][mode][g] = 1e30f;
                     continue;
                 }
                 hipStream_t st = c->stream;
@@ -615,11 +617,11 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
             if (ntrees == 2) fprintf(stderr, ", PLOC %.3f", best_total[1]);
             const char* tag = "?-LPW";
             fprintf(stderr, " -> %s; extend (lane/packet/wide ms):", t ? "PLOC" : "Karras");
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, te[t][2][g], te[t][3][g], te[t][4][g] > 1e29f ? 0.0f : te[t][4][g], tag[c->mode_extend[g]]);
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, te[t][2][g] > 1e29f ? 0.0f : te[t][2][g], te[t][3][g], te[t][4][g] > 1e29f ? 0.0f : te[t][4][g], tag[c->mode_extend[g]]);
             fprintf(stderr, "; rays:");
             for (int g = 0; g < G; g++) fprintf(stderr, " g%d %u", g, sample_rays[g]);
             fprintf(stderr, "; shadow:");
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, tsh[t][2][g], tsh[t][3][g], tsh[t][4][g] > 1e29f ? 0.0f : tsh[t][4][g], tag[c->mode_shadow[g]]);
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, tsh[t][2][g] > 1e29f ? 0.0f : tsh[t][2][g], tsh[t][3][g], tsh[t][4][g] > 1e29f ? 0.0f : tsh[t][4][g], tag[c->mode_shadow[g]]);
             fprintf(stderr, "\n");
         }
     } else {
