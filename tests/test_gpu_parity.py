@@ -437,6 +437,22 @@ def test_many_lights_degenerate_triangles_and_odd_films(oracle, tracer, w, h, sp
         assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow)
 
 
+@pytest.mark.parametrize("name,kw", [("dragon", dict(width=960, height=540, spp=4)), ("spheres2", dict(width=640, height=480, spp=2))])
+def test_repeated_frames_are_byte_identical(tracer, name, kw):
+    """Colours travel up the ray tree from whichever wave finishes a ray; every slot has one writer per
+    frame, so twenty frames in a row must not differ in a single byte (a race would flicker)."""
+    import torch
+    scene = load_scene(name).copy(seed=2, **kw)
+    tracer.load_scene(scene)
+    first = torch.empty(scene.width * scene.height * 3, dtype=torch.uint8, device="cuda:0")
+    again = torch.empty_like(first)
+    tracer.render_device(first.data_ptr())
+    for _ in range(20):
+        again.zero_()
+        tracer.render_device(again.data_ptr())
+        assert bool((first == again).all())
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
