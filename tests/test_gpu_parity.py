@@ -453,6 +453,24 @@ def test_repeated_frames_are_byte_identical(tracer, name, kw):
         assert bool((first == again).all())
 
 
+def test_render_on_a_caller_provided_stream(tracer):
+    """rt_options.stream: every launch of the context goes to the caller's HIP stream (here a torch stream),
+    so work the caller queued on it before the call is seen by the render, and the result is the same image."""
+    import torch
+    scene = load_scene("spheres2").copy(width=320, height=240, spp=2)
+    tracer.load_scene(scene)
+    want, _, _ = tracer.render()
+    stream = torch.cuda.Stream(device="cuda:0")
+    with ra.Tracer(stream=stream.cuda_stream) as t:
+        t.load_scene(scene)
+        with torch.cuda.stream(stream):
+            out = torch.full((scene.height, scene.width, 3), 7, dtype=torch.uint8, device="cuda:0")   # queued on the same stream
+            st = t.render_device(out.data_ptr())
+            got = out.cpu().numpy()
+        stream.synchronize()
+    assert np.array_equal(got, want) and st.rays > 0
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
