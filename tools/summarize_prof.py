@@ -109,8 +109,9 @@ def main():
         if os.path.exists(bj):
             # the bench line of this profile run, with the traffic its own counter passes measured
             b = json.load(open(bj))
-            if "k_extend" in entry:
-                b["roofline"]["traffic"] = entry["k_extend"]
+            dominant = b["roofline"]["kernel"].split("<")[0]           # k_extend or k_shadow
+            if dominant in entry:
+                b["roofline"]["traffic"] = entry[dominant]
             b["roofline"]["rocprofv3_kernel_trace"] = timed
             json.dump(b, open(prefix + "_bench.json", "w"))
     json.dump(timed, open(prefix + "_timed_launches.json", "w"), indent=1, sort_keys=True)
