@@ -65,7 +65,19 @@ struct rt_ctx {
     bool tuned = false, forced_modes = false;
     uint32_t tiles_cap = 0;    // batches of this scene that overflowed a pool that could not grow were split: keep to that size
     bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
-    bool two_children = false; // some material can send out a reflection AND a refraction ray: resolve passes needed
+    bool two_children = false;
+    // Overlapped pipeline for thin batches: shadow + lighting of generation g run on a second stream while
+    // the first traces generation g + 1.  The per-generation hit records and the hit list are double-buffered
+    // for it (generation parity), events order the two streams.
+    uint64_t overlap_rays = 8u << 20;      // generations expected to hold at most this many rays are overlapped (0: never)
+    int reported_first_ov = -1;            // RT_VERBOSE: the last overlap start that was printed
+    // rays per generation of a batch: what the last frame's batches held (the calibration sample, scaled, before
+    // any frame); 0 = unknown.  Only decides WHERE the overlap starts, never a result.
+    uint64_t gen_rays[RT_MAX_GEN + 2] = {0}, gen_rays_frame[RT_MAX_GEN + 2] = {0};
+    bool gen_rays_known = false;
+    hipStream_t stream2 = nullptr;
+    float4 *hp2 = nullptr, *hn2 = nullptr, *hd2 = nullptr; uint32_t* hitlist2 = nullptr; uint64_t alt_capacity = 0;
+    std::vector<hipEvent_t> ev_scan, ev_light; // some material can send out a reflection AND a refraction ray: resolve passes needed
     DScene S{};
     DCamera cam{};
     float4* d_sph = nullptr; int* d_sph_mat = nullptr;
@@ -107,6 +119,8 @@ static void free_pool(rt_ctx* c) {
     hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.link); hipFree(c->P.wstats); hipFree(c->P.occl); hipFree(c->P.scol);
     hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr); hipFree(c->P.hit_base);
     hipFree(c->P.child_base); hipFree(c->P.blocksum); hipFree(c->P.hitlist); hipFree(c->P.wq);
+    hipFree(c->hp2); hipFree(c->hn2); hipFree(c->hd2); hipFree(c->hitlist2);
+    c->hp2 = c->hn2 = c->hd2 = nullptr; c->hitlist2 = nullptr; c->alt_capacity = 0;
     c->P = DPool{};
     c->pool_capacity = c->scol_capacity = c->occl_capacity = 0;
 }
@@ -126,6 +140,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     if (opt) c->opt = *opt;
     for (int g = 0; g <= RT_MAX_GEN; g++) { c->mode_extend[g] = 3; c->mode_shadow[g] = 3; }
     if (const char* e = getenv("RT_COUNT_WORK")) c->count_work = atoi(e) != 0;
+    if (const char* e = getenv("RT_OVERLAP_RAYS")) c->overlap_rays = strtoull(e, nullptr, 10);
     if (const char* e = getenv("RT_PACKET_GENS")) {
         c->forced_modes = true;
         const int lane_mode = getenv("RT_LANE_WIDE") ? 4 : 2;      // RT_LANE_WIDE: the per-lane walks use the 4-wide tree
@@ -160,6 +175,9 @@ extern "C" void rt_destroy(rt_ctx* c) {
     free_scene(c);
     free_pool(c);
     hipFree(c->d_counters); hipFree(c->d_tiles); hipFree(c->d_rowbase); hipFree(c->d_rgb); hipFree(c->d_rgbf);
+    for (auto e : c->ev_scan) hipEventDestroy(e);
+    for (auto e : c->ev_light) hipEventDestroy(e);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -314,6 +332,8 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     }
     c->accel = accel;
     c->tuned = false;
+    c->gen_rays_known = false;
+    for (int g = 0; g <= RT_MAX_GEN; g++) c->gen_rays[g] = c->gen_rays_frame[g] = 0;
     c->tiles_cap = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_scene = true;
@@ -397,6 +417,7 @@ struct BatchResult {
     bool overflow = false;
     uint64_t secondary = 0, shadow = 0, nodes[2] = {0, 0}, sph[2] = {0, 0}, tri[2] = {0, 0}, lane_nodes[2] = {0, 0}, lane_prims[2] = {0, 0};
     int generations = 0;
+    double stage_b[4] = {0, 0, 0, 0};      // stage times of the second stream (overlapped pipeline)
 };
 
 struct StageTimes {
@@ -413,12 +434,36 @@ struct StageTimes {
         if (!on) return;
         for (size_t i = 1; i < ev.size(); i++) {
             float ms = 0; hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
-            out[cat[i]] += ms;
+            if (cat[i] >= 0) out[cat[i]] += ms;          // category -1: a wait for the other stream, nobody's time
         }
         for (auto e : ev) hipEventDestroy(e);
         ev.clear(); cat.clear();
     }
 };
+
+// What the overlapped pipeline needs beyond the pool: a second stream, one event pair per generation and
+// the second copy of the per-generation buffers.
+static int ensure_overlap(rt_ctx* c) {
+    if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    while (c->ev_scan.size() < (size_t)RT_MAX_GEN + 1) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        c->ev_scan.push_back(a);
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->ev_light.push_back(b);
+    }
+    if (c->alt_capacity < c->pool_capacity) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->hp2); hipFree(c->hn2); hipFree(c->hd2); hipFree(c->hitlist2);
+        c->hp2 = c->hn2 = c->hd2 = nullptr; c->hitlist2 = nullptr; c->alt_capacity = 0;
+        HIP_TRY(hipMalloc(&c->hp2, c->pool_capacity * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->hn2, c->pool_capacity * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->hd2, c->pool_capacity * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->hitlist2, c->pool_capacity * sizeof(uint32_t)));
+        c->alt_capacity = c->pool_capacity;
+    }
+    return RT_OK;
+}
 
 // Enqueues one batch (tiles [tile0, tile0+ntiles) of the current partition) and
 // waits for it.  All launches are asynchronous; the only host sync is the final
@@ -437,22 +482,68 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     tm.mark(3);
     if (S.max_depth < 0) rtk_fill_background(st, S, c->P, nsamples, c->max_blocks);   // nothing is traced at all
     uint64_t bound = nsamples;
+    // The generations of the batch.  Fat ones run one after the other on the context's stream (A): extend ->
+    // scan -> shadow -> shade.  From the first generation expected to be thin on (few rays: launches that last
+    // as long as their longest walk and leave most of the chip idle) the work is split over two streams:
+    //   A: extend(g) -> scan(g) -> spawn(g) -> extend(g+1) ...     B: miss(g) -> shadow(g) -> light(g)
+    // B starts a generation when its scan is done.  The colour of a ray is final only when its parent's
+    // record exists, so everything that hands colours on (the misses of generation g, the leaves among its
+    // hits) runs on B, in generation order, after the lighting of g - 1.  Buffers written per generation by A
+    // and read by B (hit records, hit list) alternate between two copies; A reuses a copy once the lighting
+    // of the generation before last has read it.
+    int first_ov = S.max_depth + 1;
+    // (brute force launches are short: the extra launches of the split would cost more than the overlap gives)
+    if (c->overlap_rays && c->accel == RT_ACCEL_LBVH && c->gen_rays_known && c->stream2 && c->alt_capacity >= cap && S.max_depth >= 1) {
+        while (first_ov > 0 && c->gen_rays[first_ov - 1] <= c->overlap_rays) first_ov--;
+        if (first_ov == S.max_depth && S.max_depth > 0) first_ov = S.max_depth + 1;     // a lone last generation has nothing to overlap with
+    }
+    const bool any_ov = first_ov <= S.max_depth;
+    if (c->reported_first_ov != first_ov && getenv("RT_VERBOSE")) {
+        if (any_ov) fprintf(stderr, "[rt overlap] generations %d..%d on two streams (expected rays there: %llu and fewer)\n", first_ov,
+                            S.max_depth, (unsigned long long)c->gen_rays[first_ov]);
+        else fprintf(stderr, "[rt overlap] none\n");
+        c->reported_first_ov = first_ov;
+    }
+    hipStream_t B = c->stream2;
+    StageTimes tmB;
+    tmB.st = B; tmB.on = tm.on && any_ov;
     for (int g = 0; g <= S.max_depth; g++) {
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
         if (c->accel == RT_ACCEL_LBVH) { acc_e = c->mode_extend[g]; acc_s = c->mode_shadow[g]; }
         if (acc_e == 4 && !S.nodes4) acc_e = 2;
         if (acc_s == 4 && !S.nodes4) acc_s = 2;
-        rtk_extend(st, acc_e, S, c->P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work);
+        const bool ov = g >= first_ov;
+        DPool P = c->P;
+        if (any_ov && (g & 1)) { P.hp = c->hp2; P.hn = c->hn2; P.hd = c->hd2; P.hitlist = c->hitlist2; }
+        if (ov && g - 2 >= first_ov) hipStreamWaitEvent(st, c->ev_light[g - 2], 0);
+        rtk_extend(st, acc_e, S, P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work, ov);
         tm.mark(0);
-        rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
+        rtk_compact(st, P, c->d_counters, g, bound, c->max_blocks);
         tm.mark(3);
-        rtk_shadow(st, acc_s, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, c->count_work);
-        tm.mark(1);
-        rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
-        tm.mark(2);
+        const uint64_t items = bound * (uint64_t)std::max(1, S.nl);
+        if (!ov) {
+            rtk_shadow(st, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work);
+            tm.mark(1);
+            rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, 0);
+            tm.mark(2);
+        } else {
+            hipEventRecord(c->ev_scan[g], st);
+            rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, 1);
+            tm.mark(2);
+            hipStreamWaitEvent(B, c->ev_scan[g], 0);
+            tmB.mark(-1);
+            if (g >= 1) rtk_miss(B, S, P, c->d_counters, g, bound, c->max_blocks);
+            tmB.mark(3);
+            rtk_shadow(B, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work);
+            tmB.mark(1);
+            rtk_shade(B, S, P, c->d_counters, g, bound, c->max_blocks, 2);
+            tmB.mark(2);
+            hipEventRecord(c->ev_light[g], B);
+        }
         bound = std::min<uint64_t>(bound * 2, cap);
     }
+    if (any_ov) { hipStreamWaitEvent(st, c->ev_light[S.max_depth], 0); tm.mark(-1); }
     for (int g = S.max_depth - 1; g >= 0 && c->two_children; g--)
         rtk_resolve(st, S, c->P, c->d_counters, g, std::min<uint64_t>((uint64_t)nsamples << std::min(g, 20), cap), c->max_blocks);
     rtk_finish(st, c->cam, c->P, c->d_tiles, tile0, npixels, shard_mode, d_out, d_outf, c->max_blocks);
@@ -462,6 +553,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     res.overflow = hc.overflow != 0;
+    tmB.collect(res.stage_b);
     if (S.profile)
         fprintf(stderr, "[rt profile] batch tiles %u: closest-hit walks %llu steps %llu walk-cycles %llu (%.0f cyc/step, %.1f steps/walk) wave-cycles %llu | any-hit walks %llu steps %llu walk-cycles %llu (%.0f cyc/step)\n",
                 ntiles, hc.prof_walks[0], hc.prof_steps[0], hc.prof_walk_cycles[0],
@@ -474,6 +566,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     if (used > cap) res.overflow = true;
     if (!res.overflow) {
         for (int g = 0; g <= S.max_depth; g++) {
+            c->gen_rays_frame[g] = std::max<uint64_t>(c->gen_rays_frame[g], hc.gen_count[g]);
             if (g > 0) res.secondary += hc.gen_count[g];
             res.shadow += (uint64_t)hc.hit_count[g] * (uint64_t)S.nl;
             if (hc.gen_count[g]) res.generations = g + 1;
@@ -603,6 +696,10 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
             else if (!strcmp(e, "ploc") && ntrees == 2) t = 1;
         }
         adopt_tree(c, t == 1);
+        // first guess of the rays per generation of a whole batch, until a frame has been counted
+        for (int g = 0; g < G; g++)
+            c->gen_rays[g] = (uint64_t)((double)sample_rays[g] * ((double)tiles_per_batch * (double)per_tile) / ((double)n * (double)per_tile));
+        c->gen_rays_known = true;
         for (int g = 0; g < G; g++) {
             // within 10 % the packet walk is kept: thin generations time within noise of each other, and a
             // choice that flips from run to run would make the work counters (fetches per ray) flip with it
@@ -672,11 +769,24 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         want_samples /= 2;
     }
     if (!c->tuned && (rc = calibrate(c, tiles_per_batch)) != RT_OK) return rc;
+    // the second copy of the per-generation buffers is worth having, not worth failing for
+    bool want_overlap = c->overlap_rays > 0 && c->S.max_depth >= 1 && c->accel == RT_ACCEL_LBVH;
+    auto try_overlap = [&]() {
+        if (!want_overlap) return;
+        if (ensure_overlap(c) != RT_OK) {
+            (void)hipGetLastError();
+            hipFree(c->hp2); hipFree(c->hn2); hipFree(c->hd2); hipFree(c->hitlist2);
+            c->hp2 = c->hn2 = c->hd2 = nullptr; c->hitlist2 = nullptr; c->alt_capacity = 0;
+            want_overlap = false;
+        }
+    };
+    try_overlap();
 
     StageTimes tm;
     tm.st = c->stream;
     tm.on = stats != nullptr && getenv("RT_STAGE_TIMES") != nullptr;
     rt_stats acc{};
+    double stage_b[4] = {0, 0, 0, 0};
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     // work list of (tile0, ntiles); an overflowing batch is split in two and retried
     std::vector<std::pair<uint32_t, uint32_t>> work;
@@ -704,6 +814,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
             if (can_grow || n == 1) {
                 rc = ensure_pool(c, bigger, c->scol_capacity);
                 if (rc != RT_OK) return rc;
+                try_overlap();
                 work.push_back({t0, n});
             } else {
                 uint32_t h = n / 2;
@@ -714,6 +825,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
             continue;
         }
         acc.batches++;
+        for (int k = 0; k < 4; k++) stage_b[k] += br.stage_b[k];
         acc.rays_secondary += br.secondary;
         acc.rays_shadow += br.shadow;
         for (int k = 0; k < 2; k++) {
@@ -726,6 +838,8 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
+    for (int g = 0; g <= RT_MAX_GEN; g++) { c->gen_rays[g] = c->gen_rays_frame[g]; c->gen_rays_frame[g] = 0; }
+    c->gen_rays_known = true;
     if (stats) {
         float ms = 0;
         hipEventElapsedTime(&ms, c->ev0, c->ev1);
@@ -740,6 +854,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         acc.ms_render = ms;
         double t4[4] = {0, 0, 0, 0};
         tm.collect(t4);
+        for (int k = 0; k < 4; k++) t4[k] += stage_b[k];
         acc.ms_extend = t4[0]; acc.ms_shadow = t4[1]; acc.ms_shade = t4[2]; acc.ms_other = t4[3];
         acc.accel_used = c->accel;
         *stats = acc;

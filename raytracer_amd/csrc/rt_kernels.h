@@ -8,13 +8,18 @@
 void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations);
 // generation 0 is generated on the fly from (cam, tiles, tile0); deeper generations read the pool
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
-                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count);
+                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count,
+                bool defer_miss = false);
 // prefix sums over the wave masks of generation g: hit list, hit / next-generation counts, child offsets
 void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C);
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks, bool count);
-void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
+// phase 0: lights + hand-over + spawn; 1: spawn only; 2: lights + hand-over only (overlapped pipeline)
+void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks,
+               int phase = 0);
+// background for the missed rays of generation g >= 1 that an extend launch with defer_miss left alone
+void rtk_miss(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_resolve(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                  int max_blocks);
 void rtk_fill_background(hipStream_t st, const DScene& S, const DPool& P, uint32_t nsamples, int max_blocks);

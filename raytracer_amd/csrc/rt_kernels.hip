@@ -646,6 +646,7 @@ struct GenSrc {        // what generation 0 is generated from
     DCamera cam;
     const uint32_t* tiles;
     uint32_t tile0;
+    int defer_miss;    // 1: misses of generations >= 1 are delivered later by k_miss (overlapped pipeline)
 };
 __device__ __forceinline__ RayRec load_ray(const DPool& P, const GenSrc& G, int g, uint32_t i, uint32_t r) {
     RayRec R;
@@ -740,7 +741,8 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
     // travels while the hit lanes of the wave build their records
     const bool miss = active && !hit;
     float4 ploc = make_float4(0, 0, 0, 0);
-    if (miss && g > 0) ploc = P.loc[R.parent];
+    const bool deliver_now = miss && !(G.defer_miss && g > 0);
+    if (deliver_now && g > 0) ploc = P.loc[R.parent];
     if (hit) {
         F3 point, normal; int mat;
         make_hit_uv(S, o, d, best, uv, point, normal, mat);
@@ -753,7 +755,7 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
             refl = sp.refl; refr = sp.refr;
         }
     }
-    if (miss) deliver_from(S, P, g, R.parent, R.slot, S.bg, ploc);
+    if (deliver_now) deliver_from(S, P, g, R.parent, R.slot, S.bg, ploc);
     unsigned long long mh = __ballot(hit), m1 = __ballot(refl), m2 = __ballot(refr);
     if ((threadIdx.x & 63) == 0 && inrange) {
         uint32_t grp = gbase + (i >> 6);
@@ -853,7 +855,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
                         bits |= (spn.refl ? 2u : 0u) | (spn.refr ? 4u : 0u);
                     }
                 } else {
-                    if (valid) deliver(S, P, g, parent, slot, S.bg);
+                    if (valid && !(G.defer_miss && g > 0)) deliver(S, P, g, parent, slot, S.bg);
                 }
                 flags[k] = (uint8_t)bits;
                 state = IDLE;
@@ -1147,7 +1149,11 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
 // generation are written at the offsets the scan assigned (or, past max_depth,
 // the background is added directly as evaluateRayTree :132-135 returns it
 // without tracing).
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES))) void k_shade(DScene S, DPool P, DCounters* C, int g) {
+// PHASE 0: the whole of getColor; 1: only the spawn (child rays; no lights, so few registers: 8 waves per
+// SIMD); 2: only the colour (lights, hand-over).  1 and 2 together do what 0 does, for the overlapped pipeline.
+template <int PHASE>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ? 1 : RT_SHADE_WAVES, PHASE == 1 ? 8 : RT_SHADE_WAVES))) void k_shade(DScene S, DPool P, DCounters* C, int g) {
+    constexpr int phase = PHASE;
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
@@ -1177,7 +1183,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
         float ns = m0.w, iorf = m1.w;
         float rval = m0.x, gval = m0.y, bval = m0.z;
         rval *= S.ambient.x; gval *= S.ambient.y; bval *= S.ambient.z;
-        for (int j = 0; j < S.nl; j++) {
+        for (int j = 0; j < (phase == 1 ? 0 : S.nl); j++) {
             const DLight L = S.lights[j];
             if (P.occl[(uint64_t)h * (uint32_t)S.nl + j]) continue;
             F3 I; float dist2f;
@@ -1219,11 +1225,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
             leaf = true;
         }
         if (leaf) {
-            deliver(S, P, g, parent, slot, f3(rval, gval, bval));
+            if (phase != 1) deliver(S, P, g, parent, slot, f3(rval, gval, bval));
             continue;
         }
         uint32_t code = ((uint32_t)mat << 2) | (sp.refl ? 1u : 0u) | (sp.refr ? 2u : 0u);
-        P.loc[r] = make_float4(rval, gval, bval, bitsf(code));
+        if (phase != 1) P.loc[r] = make_float4(rval, gval, bval, bitsf(code));
+        if (phase == 2) continue;
         // where the scan put this ray's children: rays of the group before it first
         const unsigned long long below = (1ull << (i & 63u)) - 1ull;
         uint64_t at = (uint64_t)next_start + cbase + (uint32_t)__popcll(mrefl & below) + (uint32_t)__popcll(mrefr & below);
@@ -1244,6 +1251,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHA
             P.d[at] = make_float4(rad.x, rad.y, rad.z, bitsf(1u));
             P.link[at] = r | 0x80000000u;
         }
+    }
+}
+
+// ---------------------------------------------------------------- deferred misses
+// The background for the rays of generation g >= 1 that hit nothing, when the extend kernel was told
+// to leave them (overlapped pipeline: the parents' records may not be written yet while it runs).
+__global__ __launch_bounds__(RT_BLOCK) void k_miss(DScene S, DPool P, DCounters* C, int g) {
+    if (C->overflow) return;
+    const uint32_t start = gen_start(C, g);
+    const uint32_t count = gen_size(C, g, start, P.capacity);
+    const uint32_t gbase = C->gbase[g];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        if ((P.mask_hit[gbase + (i >> 6)] >> (i & 63u)) & 1ull) continue;
+        const uint32_t link = P.link[start + i];
+        deliver(S, P, g, link & 0x7FFFFFFFu, link >> 31, S.bg);
     }
 }
 
@@ -1423,8 +1445,9 @@ static void launch_extend(hipStream_t st, int accel, const DScene& S, const DPoo
     else hipLaunchKernelGGL((k_extend<3, COUNT>), grid, block, 0, st, S, P, C, G, g);
 }
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
-                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count) {
-    GenSrc G{cam, tiles, tile0};
+                const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count,
+                bool defer_miss) {
+    GenSrc G{cam, tiles, tile0, defer_miss ? 1 : 0};
     if (count || S.profile) launch_extend<true>(st, accel, S, P, C, G, g, bound, max_blocks);
     else launch_extend<false>(st, accel, S, P, C, G, g, bound, max_blocks);
 }
@@ -1457,8 +1480,14 @@ void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
     else launch_shadow<false>(st, accel, S, P, C, g, bound, max_blocks);
 }
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
-               int max_blocks) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
+               int max_blocks, int phase) {
+    dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
+    if (phase == 1) hipLaunchKernelGGL(k_shade<1>, grid, block, 0, st, S, P, C, g);
+    else if (phase == 2) hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, S, P, C, g);
+    else hipLaunchKernelGGL(k_shade<0>, grid, block, 0, st, S, P, C, g);
+}
+void rtk_miss(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {
+    hipLaunchKernelGGL(k_miss, dim3(grid_for(bound, max_blocks)), dim3(RT_BLOCK), 0, st, S, P, C, g);
 }
 void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C) {
     hipLaunchKernelGGL(k_reduce_stats, dim3(10), dim3(256), 0, st, P, C);
