@@ -516,7 +516,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         const bool ov = g >= first_ov;
         DPool P = c->P;
         if (any_ov && (g & 1)) { P.hp = c->hp2; P.hn = c->hn2; P.hd = c->hd2; P.hitlist = c->hitlist2; }
-        if (ov && g - 2 >= first_ov) hipStreamWaitEvent(st, c->ev_light[g - 2], 0);
+        if (ov && g - 2 >= first_ov) { hipStreamWaitEvent(st, c->ev_light[g - 2], 0); tm.mark(-1); }
         rtk_extend(st, acc_e, S, P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work, ov);
         tm.mark(0);
         rtk_compact(st, P, c->d_counters, g, bound, c->max_blocks);
