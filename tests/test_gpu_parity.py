@@ -471,6 +471,26 @@ def test_render_on_a_caller_provided_stream(tracer):
     assert np.array_equal(got, want) and st.rays > 0
 
 
+@pytest.mark.parametrize("name,kw", [("dragon", dict(width=640, height=360, spp=4)),
+                                     ("spheres2", dict(width=480, height=360, spp=3)),          # reflection AND refraction: resolve passes
+                                     ("plant_h_smooth", dict(width=330, height=256, spp=2, max_depth=8))])
+def test_two_stream_generations_render_the_same_image(monkeypatch, name, kw):
+    """Thin generations run split over two streams (shadow + lighting of generation g beside the traversal of
+    g + 1).  Whatever the split -- none, from the first generation on, from a later one -- the frame is the same."""
+    scene = load_scene(name).copy(seed=3, **kw)
+    images = []
+    for threshold in ("0", str(1 << 40), "20000"):
+        monkeypatch.setenv("RT_OVERLAP_RAYS", threshold)
+        with ra.Tracer(accel=ra.RT_ACCEL_LBVH) as t:
+            t.load_scene(scene)
+            for _ in range(3):                       # the split follows the ray counts of the frame before
+                rgb, rgbf, st = t.render(want_float=True)
+            images.append((rgb, rgbf, st))
+    for rgb, rgbf, st in images[1:]:
+        assert np.array_equal(rgb, images[0][0]) and np.array_equal(bits(rgbf), bits(images[0][1]))
+        assert st.rays == images[0][2].rays
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
