@@ -98,7 +98,10 @@ typedef struct rt_options {
     int32_t batch_samples;     /* pixel-samples per wavefront batch, 0 = default (128 Mi,
                                   halved while the pool does not fit in device memory)   */
     int64_t pool_rays;         /* ray-pool capacity per batch, 0 = default (4 x batch)  */
-    void* stream;              /* hipStream_t to run on, NULL = a stream the ctx owns   */
+    void* stream;              /* hipStream_t to run on, NULL = a stream the ctx owns.
+                                * Work queued on it before a call is seen by the call, and every call
+                                * returns with its work on it complete.  Thin ray generations also use a
+                                * second, internal stream that forks from and joins this one inside the call. */
 } rt_options;
 
 typedef struct rt_stats {
