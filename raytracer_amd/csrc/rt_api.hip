@@ -529,8 +529,10 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
             tm.mark(2);
         } else {
             hipEventRecord(c->ev_scan[g], st);
-            rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, 1);
-            tm.mark(2);
+            if (g < S.max_depth) {                      // the last generation sends out no rays
+                rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, 1);
+                tm.mark(2);
+            }
             hipStreamWaitEvent(B, c->ev_scan[g], 0);
             tmB.mark(-1);
             if (g >= 1) rtk_miss(B, S, P, c->d_counters, g, bound, c->max_blocks);
