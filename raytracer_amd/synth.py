@@ -1,4 +1,4 @@
-"""Synthetic large scene of BASELINE config 5 ("1M spheres + 10M triangles"), built directly
+"""Synthetic large scene of the fifth benchmark configuration ("1M spheres + 10M triangles"), built directly
 as arrays (a text .scn of that size would be ~0.7 GB and the reference parser is O(N^2)).
 
 Deterministic for a given (seed, scale): scale = 1.0 is the full 10^6 spheres + 10^7

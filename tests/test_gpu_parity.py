@@ -186,7 +186,7 @@ def test_sharded_render_is_byte_identical_for_any_world_size(tracer, world):
 
 
 def test_synthetic_scene_small_scale_against_oracle(oracle, tracer):
-    """BASELINE config 5 at 1/1000 scale (10^3 spheres + 10^4 triangles): LBVH render vs the oracle."""
+    """The fifth benchmark configuration at 1/1000 scale (10^3 spheres + 10^4 triangles): LBVH render vs the oracle."""
     from raytracer_amd.synth import synthetic_scene
     scene = synthetic_scene(scale=0.001, width=160, height=90, spp=2)
     tracer.load_scene(scene)
