@@ -210,6 +210,11 @@ static void compute_camera(const rt_scene_desc& s, DCamera& cam) {
     cam.width = s.width; cam.height = s.height; cam.spp = s.spp; cam.proj = s.proj;
     cam.seed = s.seed;
     cam.inv_w = 1.0 / (double)s.width; cam.inv_h = 1.0 / (double)s.height;
+    cam.spp_shift = -1;
+    for (int k = 0; k < 31; k++) if (s.spp == (1 << k)) cam.spp_shift = k;
+    // jitter counter = ((y*W + x)*spp + j)*2 + k, largest value below W*H*spp*2
+    cam.counter32 = ((double)s.width * (double)s.height * (double)s.spp * 2.0 <= 4294967296.0) ? 1u : 0u;
+    cam.jitter_hi0 = rt_lowbias32(s.seed * 0x9E3779B9U + 0x85EBCA6BU);
 }
 
 // ---------------------------------------------------------------- scene upload

@@ -56,6 +56,10 @@ struct DCamera {
     int width, height, spp, proj;
     uint32_t seed;
     double inv_w, inv_h;   // 1.0 / width, 1.0 / height, correctly rounded (see rt_cdiv)
+    // frame constants that shorten the per-sample integer work: log2(spp) when spp is a power of two (else
+    // -1), and, when the jitter counter of the whole film fits 32 bits, the hash of its (zero) high word
+    int spp_shift;
+    uint32_t counter32, jitter_hi0;
 };
 
 // a / b, correctly rounded, for a divisor whose reciprocal y = RN(1 / b) is at hand: two

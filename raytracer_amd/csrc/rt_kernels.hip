@@ -617,11 +617,23 @@ __device__ __forceinline__ void pixel_of(const uint32_t* __restrict__ tiles, uin
 __device__ __forceinline__ void primary_ray(const DCamera& cam, int x, int y, int j, F3& o, F3& d) {
     double r1, r2;
     if (cam.spp > 1) {
-        unsigned long long c = (((unsigned long long)y * (unsigned long long)cam.width +
-                                 (unsigned long long)x) * (unsigned long long)cam.spp +
-                                (unsigned long long)j) * 2ull;
-        r1 = rt_cdiv((double)(int)rt_jitter(cam.seed, c), 2147483647.0, 1.0 / 2147483647.0);
-        r2 = rt_cdiv((double)(int)rt_jitter(cam.seed, c + 1), 2147483647.0, 1.0 / 2147483647.0);
+        uint32_t j1, j2;
+        if (cam.counter32) {
+            // the counter of every sample of this film fits 32 bits: its high word is zero and that word's
+            // hash a frame constant (rt_jitter with the same result, four quarter-rate multiplies fewer)
+            const uint32_t pix = (uint32_t)y * (uint32_t)cam.width + (uint32_t)x;
+            const uint32_t c32 = ((cam.spp_shift >= 0 ? pix << cam.spp_shift : pix * (uint32_t)cam.spp) + (uint32_t)j) << 1;
+            j1 = rt_lowbias32(c32 ^ cam.jitter_hi0) >> 1;
+            j2 = rt_lowbias32((c32 + 1u) ^ cam.jitter_hi0) >> 1;
+        } else {
+            unsigned long long c = (((unsigned long long)y * (unsigned long long)cam.width +
+                                     (unsigned long long)x) * (unsigned long long)cam.spp +
+                                    (unsigned long long)j) * 2ull;
+            j1 = rt_jitter(cam.seed, c);
+            j2 = rt_jitter(cam.seed, c + 1);
+        }
+        r1 = rt_cdiv((double)(int)j1, 2147483647.0, 1.0 / 2147483647.0);
+        r2 = rt_cdiv((double)(int)j2, 2147483647.0, 1.0 / 2147483647.0);
     } else {
         r1 = r2 = .5;
     }
@@ -651,8 +663,9 @@ struct GenSrc {        // what generation 0 is generated from
 __device__ __forceinline__ RayRec load_ray(const DPool& P, const GenSrc& G, int g, uint32_t i, uint32_t r) {
     RayRec R;
     if (g == 0) {
-        uint32_t lp = i / (uint32_t)G.cam.spp;
-        int j = (int)(i - lp * (uint32_t)G.cam.spp);
+        uint32_t lp; int j;
+        if (G.cam.spp_shift >= 0) { lp = i >> G.cam.spp_shift; j = (int)(i & ((1u << G.cam.spp_shift) - 1u)); }
+        else { lp = i / (uint32_t)G.cam.spp; j = (int)(i - lp * (uint32_t)G.cam.spp); }
         int x, y, px, py; uint32_t tile;
         pixel_of(G.tiles, G.tile0, lp, x, y, px, py, tile);
         R.valid = x < G.cam.width && y < G.cam.height;

@@ -491,6 +491,23 @@ def test_two_stream_generations_render_the_same_image(monkeypatch, name, kw):
         assert st.rays == images[0][2].rays
 
 
+@pytest.mark.parametrize("w,h,spp", [(60000, 50000, 4), (60000, 50000, 3), (4099, 2053, 64), (3840, 2160, 16), (641, 479, 5)])
+def test_primary_rays_for_every_counter_and_sample_rate_shortcut(oracle, tracer, w, h, spp):
+    """Sample index -> pixel and the jitter draw take shortcuts when sample_rate is a power of two and when
+    the jitter counter of the whole film fits 32 bits; the first two films here need 64 bits.  All must give
+    the oracle's rays bit for bit, also for the last pixels of the film (the largest counters)."""
+    scene = load_scene("spheres1").copy(width=w, height=h, spp=spp, seed=77)
+    tracer.load_scene(scene)
+    rng = np.random.default_rng(w + spp)
+    xs = np.concatenate([rng.integers(0, w, 60), [0, w - 1, w - 1]]).astype(np.int32)
+    ys = np.concatenate([rng.integers(0, h, 60), [0, h - 1, h - 2]]).astype(np.int32)
+    js = np.concatenate([rng.integers(0, spp, 60), [0, spp - 1, 0]]).astype(np.int32)
+    o, d = tracer.primary_rays(xs, ys, js)
+    for k in range(len(xs)):
+        oo, od = oracle.get_ray(scene, int(xs[k]), int(ys[k]), int(js[k]))
+        assert np.array_equal(bits(o[k]), bits(oo)) and np.array_equal(bits(d[k]), bits(od)), (xs[k], ys[k], js[k])
+
+
 def test_negative_max_depth_returns_the_background_untraced(oracle, tracer):
     # src/raytrace.cpp:132-135: depth 0 > max_depth, so no ray is traced at all
     s = load_scene("spheres1").copy(width=50, height=40, spp=3, max_depth=-1)
