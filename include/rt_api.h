@@ -88,13 +88,20 @@ typedef struct rt_scene_desc {
     const int32_t* tri_mat;    /* [n_triangles]              */
     const float* materials;    /* [n_materials][14]          */
     const rt_light* lights;    /* [n_lights]                 */
+    /* `bvh_threshold n` / `bvh_depth n` of the scene file (src/parse.cpp:252-261), 0 = not given.
+     * The reference meant the threshold as its brute-force <-> BVH switch (`getNumObjects() >
+     * getBVHThreshold()`, the commented-out block at src/raytrace.cpp:61-69); with RT_ACCEL_AUTO
+     * and rt_options.lbvh_threshold == 0 it plays that role here.  bvh_depth is carried but
+     * unused: the LBVH has no depth cap. */
+    int32_t bvh_threshold;
+    int32_t bvh_depth;
 } rt_scene_desc;
 
 typedef struct rt_options {
     int32_t device;            /* HIP device ordinal                                    */
     int32_t accel;             /* RT_ACCEL_*; AUTO = brute force (LDS-staged) for small
                                   scenes, LBVH above lbvh_threshold primitives          */
-    int32_t lbvh_threshold;    /* 0 = default (64)                                      */
+    int32_t lbvh_threshold;    /* 0 = the scene's bvh_threshold if it gives one, else 64 */
     int32_t batch_samples;     /* pixel-samples per wavefront batch, 0 = default (128 Mi,
                                   halved while the pool does not fit in device memory)   */
     int64_t pool_rays;         /* ray-pool capacity per batch, 0 = default (4 x batch)  */
@@ -141,6 +148,12 @@ const char* rt_strerror(int status);
 /* Text of the last failure on this thread (HIP error string, parse message ...). */
 const char* rt_last_error(void);
 
+/* The host-side checks rt_load_scene applies to a descriptor before anything touches the
+ * device (needs no GPU): RT_ERR_INVALID for non-positive film / sample rate, negative counts, a
+ * positive count with a NULL array, a material index out of range; RT_ERR_UNSUPPORTED for
+ * max_depth > 63, more than 2^26 primitives, 2^29 or more materials, a film beyond 65535 tiles a side. */
+int rt_validate_scene(const rt_scene_desc* scene);
+
 /* Replaces the by-value reads of `Scene&` (src/parse.h:311-327): packs the scene
  * as SoA in HBM and, when selected, builds the LBVH that stands where the
  * reference's BVH::make stood (src/raytrace.cpp:51-58, :652-788). */
@@ -152,6 +165,13 @@ int rt_load_scene(rt_ctx* ctx, const rt_scene_desc* scene);
  * alpha byte.  rgbf_out (may be NULL): width*height*3 floats, the averaged colour
  * before quantisation.  Both are HOST pointers. */
 int rt_render(rt_ctx* ctx, uint8_t* rgb_out, float* rgbf_out, rt_stats* stats);
+
+/* Progress of rt_render / rt_render_device / rt_render_shard: fn(user, pixels_done, pixels_total)
+ * is called on the calling thread before the first batch (pixels_done = 0) and after every batch
+ * of the frame.  Stands where the reference prints its `0%` ... `90%` lines from inside the pixel
+ * loop (src/raytrace.cpp:97-103).  fn = NULL removes it. */
+typedef void (*rt_progress_fn)(void* user, uint64_t pixels_done, uint64_t pixels_total);
+int rt_set_progress_callback(rt_ctx* ctx, rt_progress_fn fn, void* user);
 
 /* Same frame, but the result stays in device memory (d_rgb: width*height*3 bytes,
  * device pointer).  This is what bench.py times. */
@@ -174,6 +194,14 @@ int rt_render_shard(rt_ctx* ctx, int rank, int world, void* d_shard, rt_stats* s
  * d_rgb: width*height*3 bytes (device). */
 int rt_assemble_shards(rt_ctx* ctx, const void* d_all, int world, void* d_rgb);
 
+/* One frame on n GPUs from ONE process: ctxs[r] (any devices, the same scene loaded into each)
+ * renders shard r of n on a host thread of its own, the shards are copied to ctxs[0]'s device
+ * (peer copies) and assembled there; rgb_out is a HOST buffer of width*height*3 bytes.  stats (may
+ * be NULL): ray counts summed over the shards, ms_render = the slowest shard.  The in-process
+ * counterpart of the reference's OpenMP pixel loop (src/raytrace.cpp:92-96); byte-identical to
+ * rt_render for every n. */
+int rt_render_multi(rt_ctx* const* ctxs, int n, uint8_t* rgb_out, rt_stats* stats);
+
 /* -------------------------------------------------------- query utilities */
 /* Closest-hit / any-hit queries on caller-supplied rays (host pointers), used to
  * validate the LBVH against brute force.  o,d: [n][3].  dmax: [n] squared
@@ -186,6 +214,10 @@ int rt_query_rays(rt_ctx* ctx, int64_t n, const float* o, const float* d, const 
  * later renders count node / primitive fetches and tests into rt_stats; off by default.
  * The image does not depend on it. */
 int rt_set_work_counters(rt_ctx* ctx, int on);
+/* Measurement hook: on != 0 makes later renders fill rt_stats.ms_extend / ms_shadow / ms_shade /
+ * ms_other (HIP events between the stage launches; the environment variable RT_STAGE_TIMES
+ * does the same for every context). */
+int rt_set_stage_times(rt_ctx* ctx, int on);
 /* Primary ray of (x[i], y[i], sample j[i]) -- RayTrace::getRay (src/raytrace.cpp:441-485). */
 int rt_primary_rays(rt_ctx* ctx, int64_t n, const int32_t* x, const int32_t* y, const int32_t* j,
                     float* o_out, float* d_out);

@@ -255,6 +255,13 @@ double ref_render(unsigned seed, int x0, int y0, int x1, int y1, int nthreads,
     return el.count();
 }
 
+// The reference's own scene dump (printScene, src/parse.cpp:791-865; what its DEBUG build prints
+// after parsing, src/main.cpp:50-53) of the loaded scene, to stdout.
+void ref_print_scene() {
+    printScene(g_scene);
+    fflush(stdout);
+}
+
 // Image::Write of an RGB8 top-first buffer through the reference's own Image +
 // EasyBMP (src/image.cpp:109-124) -- used to pin the product's BMP writer byte for byte.
 void ref_write_bmp(const char* path, const unsigned char* rgb8, int w, int h) {

@@ -267,6 +267,23 @@ int orc_intersect(const orc_scene* s, const float o[3], const float d[3], double
 /* ------------------------------------------------------------------ shading */
 static v3 eval_ray_tree(const orc_scene* s, v3 rp, v3 rd, int depth, orc_counts* cnt);
 
+/* How often each branch of the spot-light fall-off (src/raytrace.cpp:552-565) was taken since the
+ * last reset: [0] alpha < angle1, [1] alpha > angle2, [2] interpolated.  Lets a test prove that a
+ * scene exercises all three. */
+static unsigned long long g_spot_branch[3];
+void orc_spot_branch_counts(unsigned long long out[3], int reset) {
+    for (int k = 0; k < 3; k++) {
+        out[k] = g_spot_branch[k];
+        if (reset) g_spot_branch[k] = 0;
+    }
+}
+static void spot_branch(int k) {
+#ifdef _OPENMP
+    #pragma omp atomic
+#endif
+    g_spot_branch[k]++;
+}
+
 /* RayTrace::getColor (src/raytrace.cpp:488-632) */
 static v3 get_color(const orc_scene* s, const hit_t* i, int depth, orc_counts* cnt) {
     mat_t m = mat_at(s, i->mat);
@@ -303,10 +320,13 @@ static v3 get_color(const orc_scene* s, const hit_t* i, int depth, orc_counts* c
         } else if (L->type == ORC_SPOT) {
             double alpha = acos(cosAlpha);
             if (alpha < L->angle1) {
+                spot_branch(0);
                 illum = vmul(vld(L->color), (float)(1.0 / dist));
             } else if (alpha > L->angle2) {
+                spot_branch(1);
                 illum = V(0, 0, 0);
             } else {
+                spot_branch(2);
                 double amt = 1 - ((alpha - L->angle1) / (L->angle2 - L->angle1));
                 illum = vmul(vld(L->color), (float)((1.0 / dist) * amt));
             }

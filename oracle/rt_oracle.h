@@ -80,6 +80,10 @@ int orc_intersect(const orc_scene* s, const float o[3], const float d[3], double
 void orc_trace_ray(const orc_scene* s, const float o[3], const float d[3], int depth, float rgb[3],
                    orc_counts* counts);
 
+/* times each branch of the spot-light fall-off ran since the last reset
+ * (src/raytrace.cpp:552 alpha < angle1, :556 alpha > angle2, :560 interpolated) */
+void orc_spot_branch_counts(unsigned long long out[3], int reset);
+
 /* Pixel::SetClamp(c*255.0) (src/pixel.cpp:38-43, src/pixel.h:17-18) */
 void orc_quantise(const float rgb[3], uint8_t out[3]);
 

@@ -49,7 +49,8 @@ class RtSceneDesc(C.Structure):
                 ("n_lights", C.c_int32),
                 ("spheres", C.c_void_p), ("sphere_mat", C.c_void_p), ("tri_verts", C.c_void_p),
                 ("tri_normals", C.c_void_p), ("tri_flags", C.c_void_p), ("tri_mat", C.c_void_p),
-                ("materials", C.c_void_p), ("lights", C.c_void_p)]
+                ("materials", C.c_void_p), ("lights", C.c_void_p),
+                ("bvh_threshold", C.c_int32), ("bvh_depth", C.c_int32)]
 
 
 class RtOptions(C.Structure):
@@ -76,6 +77,8 @@ class RtStats(C.Structure):
                 for n, _ in self._fields_}
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
+
 _lib = None
 
 
@@ -95,7 +98,11 @@ def load_library():
         "rt_destroy": (None, [vp]),
         "rt_strerror": (C.c_char_p, [C.c_int]),
         "rt_last_error": (C.c_char_p, []),
+        "rt_validate_scene": (C.c_int, [C.POINTER(RtSceneDesc)]),
         "rt_load_scene": (C.c_int, [vp, C.POINTER(RtSceneDesc)]),
+        "rt_set_progress_callback": (C.c_int, [vp, PROGRESS_FN, vp]),
+        "rt_set_stage_times": (C.c_int, [vp, C.c_int]),
+        "rt_render_multi": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.POINTER(RtStats)]),
         "rt_render": (C.c_int, [vp, vp, vp, C.POINTER(RtStats)]),
         "rt_render_device": (C.c_int, [vp, vp, C.POINTER(RtStats)]),
         "rt_shard_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -123,7 +130,8 @@ EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_strerror", "rt_last_error", "rt_load_scene", "rt_render",
     "rt_render_device", "rt_shard_tiles", "rt_shard_bytes", "rt_render_shard", "rt_assemble_shards",
     "rt_query_rays", "rt_primary_rays", "rt_jitter_hash", "rt_parse_scene_file", "rt_free_scene",
-    "rt_output_name", "rt_write_bmp24", "rt_set_work_counters",
+    "rt_output_name", "rt_write_bmp24", "rt_set_work_counters", "rt_validate_scene", "rt_set_progress_callback",
+    "rt_set_stage_times", "rt_render_multi",
 ]
 
 
@@ -156,6 +164,8 @@ class SceneArrays:
         [[0, 0, 0, 1, 1, 1, 0, 0, 0, 5, 0, 0, 0, 1]], np.float32))
     lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 12), np.float32))  # type,col3,pos3,dir3,a1,a2
     output_name: str = "raytraced.bmp"
+    bvh_threshold: int = 0      # `bvh_threshold n` of the scene file, 0 = not given
+    bvh_depth: int = 0
 
     _ARRAYS = ("cam_pos", "cam_dir", "cam_up", "background", "ambient", "spheres", "sphere_mat",
                "tri_verts", "tri_normals", "tri_flags", "tri_mat", "materials", "lights")
@@ -197,12 +207,14 @@ class SceneArrays:
         d.tri_flags, d.tri_mat = _ptr(self.tri_flags).value, _ptr(self.tri_mat).value
         d.materials = _ptr(self.materials).value
         d.lights = C.cast(la, C.c_void_p).value
+        d.bvh_threshold, d.bvh_depth = int(self.bvh_threshold), int(self.bvh_depth)
         return d, (la, self)
 
     def copy(self, **changes) -> "SceneArrays":
         kw = {n: np.array(getattr(self, n), copy=True) for n in self._ARRAYS}
         kw.update({n: getattr(self, n) for n in self._SCALARS})
         kw["output_name"] = self.output_name
+        kw["bvh_threshold"], kw["bvh_depth"] = self.bvh_threshold, self.bvh_depth
         kw.update(changes)
         return SceneArrays(**kw).normalise()
 
@@ -211,13 +223,17 @@ class SceneArrays:
         np.savez_compressed(path, **{n: getattr(self, n) for n in self._ARRAYS},
                             scalars=np.array([self.width, self.height, self.spp, self.max_depth, self.proj, self.seed], np.int64),
                             cam_half_angle=np.float32(self.cam_half_angle),
-                            output_name=np.frombuffer(self.output_name.encode(), np.uint8))
+                            output_name=np.frombuffer(self.output_name.encode(), np.uint8),
+                            **({"bvh": np.array([self.bvh_threshold, self.bvh_depth], np.int64)}
+                               if (self.bvh_threshold or self.bvh_depth) else {}))
 
     @classmethod
     def load(cls, path: str) -> "SceneArrays":
         z = np.load(path, allow_pickle=False)
         sc = z["scalars"]
         kw = {n: z[n] for n in cls._ARRAYS}
+        if "bvh" in z.files:
+            kw["bvh_threshold"], kw["bvh_depth"] = int(z["bvh"][0]), int(z["bvh"][1])
         return cls(width=int(sc[0]), height=int(sc[1]), spp=int(sc[2]), max_depth=int(sc[3]), proj=int(sc[4]),
                    seed=int(sc[5]), cam_half_angle=float(z["cam_half_angle"]),
                    output_name=bytes(z["output_name"]).decode(), **kw).normalise()
@@ -246,7 +262,7 @@ class SceneArrays:
                    tri_normals=arr(d.tri_normals, d.n_triangles, np.float32, 9),
                    tri_flags=arr(d.tri_flags, d.n_triangles, np.int32), tri_mat=arr(d.tri_mat, d.n_triangles, np.int32),
                    materials=arr(d.materials, d.n_materials, np.float32, 14), lights=lights,
-                   output_name=output_name).normalise()
+                   output_name=output_name, bvh_threshold=d.bvh_threshold, bvh_depth=d.bvh_depth).normalise()
 
 
 def parse_scene_file(path: str, ref_compat: bool = False) -> SceneArrays:
@@ -279,6 +295,27 @@ def write_bmp24(path: str, rgb: np.ndarray) -> None:
     rc = lib.rt_write_bmp24(os.fsencode(path), _ptr(rgb), w, h)
     if rc != RT_OK:
         raise RtError(rc, f"rt_write_bmp24({path})")
+
+
+def validate_scene(scene: "SceneArrays") -> int:
+    """The host-side descriptor checks of rt_load_scene (no GPU needed) -> status code."""
+    d, keep = scene.desc()
+    rc = int(load_library().rt_validate_scene(C.byref(d)))
+    del keep
+    return rc
+
+
+def render_multi(tracers, want_stats: bool = True):
+    """One frame over several Tracer contexts of this process (rt_render_multi) -> (rgb8 [H,W,3], RtStats)."""
+    lib = load_library()
+    s = tracers[0].scene
+    rgb = np.zeros((s.height, s.width, 3), np.uint8)
+    arr = (C.c_void_p * len(tracers))(*[t._ctx for t in tracers])
+    st = RtStats()
+    rc = lib.rt_render_multi(arr, len(tracers), _ptr(rgb), C.byref(st))
+    if rc != RT_OK:
+        raise RtError(rc, "rt_render_multi")
+    return rgb, st
 
 
 def jitter_hash(seed: int, counter: int) -> int:
@@ -361,6 +398,19 @@ class Tracer:
         rc = self._lib.rt_assemble_shards(self._ctx, d_all, world, d_rgb)
         if rc != RT_OK:
             raise RtError(rc, "rt_assemble_shards")
+
+    def set_stage_times(self, on: bool):
+        """Fill RtStats.ms_extend / ms_shadow / ms_shade / ms_other from the next render on."""
+        rc = self._lib.rt_set_stage_times(self._ctx, 1 if on else 0)
+        if rc != RT_OK:
+            raise RtError(rc, "rt_set_stage_times")
+
+    def set_progress_callback(self, fn):
+        """fn(pixels_done, pixels_total) before the first and after every batch of a render; None removes it."""
+        self._progress = PROGRESS_FN(lambda user, done, total: fn(int(done), int(total))) if fn else C.cast(None, PROGRESS_FN)
+        rc = self._lib.rt_set_progress_callback(self._ctx, self._progress, None)
+        if rc != RT_OK:
+            raise RtError(rc, "rt_set_progress_callback")
 
     def set_work_counters(self, on: bool):
         """Count node / primitive fetches and tests into RtStats from the next render on (slower)."""

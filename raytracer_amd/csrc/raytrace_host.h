@@ -4,8 +4,10 @@
 //   Scene::parseScene(char*)        -> 1 on success, -1 on failure  (src/parse.cpp:92-271)
 //   RayTrace::rayTrace(Scene&)      -> new Image*, caller deletes   (src/raytrace.cpp:44-129)
 //   Image::Write(char*)             -> 24-bit BMP                   (src/image.cpp:109-124)
-// Nothing here computes a pixel on the CPU: rayTrace() forwards to rt_render and
-// returns nullptr (after printing the library's error) when no GPU path exists.
+//   printScene(Scene*)              -> the DEBUG build's scene dump (src/parse.cpp:791-953)
+// Nothing here computes a pixel on the CPU: rayTrace() forwards to rt_render (or, for several
+// GPUs, rt_render_multi) and returns nullptr (after printing the library's error) when no GPU
+// path exists.
 #pragma once
 
 #include <cstdint>
@@ -46,33 +48,43 @@ class Scene {
     ~Scene();
     Scene(const Scene&) = delete;
     Scene& operator=(const Scene&) = delete;
-    // flags: RT_PARSE_REF_COMPAT to reproduce film_resolution W H -> W x W
-    int parseScene(char* file, int flags = 0);
+    // flags: RT_PARSE_REF_COMPAT reproduces film_resolution W H -> W x W (src/parse.cpp:119)
+    int parseScene(char* file, int flags = RT_PARSE_REF_COMPAT);
     rt::Image getImage() const { return img; }
     int getDepth() const;
     int getSampleRate() const;
     void setSeed(uint32_t seed);
     void setFilm(int w, int h);
     void setSampleRate(int spp);
-    const rt_scene_desc* desc() const { return d; }
+    const rt_scene_desc* desc() const { return d ? &edited : nullptr; }
   private:
     rt_scene_desc* d = nullptr;   // owned by the library (rt_free_scene)
     rt_scene_desc edited{};       // copy with caller overrides applied
-    bool use_edited = false;
     rt::Image img;
     friend class RayTrace;
 };
 
+// the scene dump of the reference's DEBUG build (src/main.cpp:50-53 -> printScene, src/parse.cpp:791-953)
+void printScene(Scene* scn);
+
 class RayTrace {
   public:
     RayTrace();
-    explicit RayTrace(int accel);
+    // accel: RT_ACCEL_*; gpus: devices 0 .. gpus-1, one context and one host thread each
+    explicit RayTrace(int accel, int gpus = 1);
     ~RayTrace();
+    RayTrace(const RayTrace&) = delete;
+    RayTrace& operator=(const RayTrace&) = delete;
     Image* rayTrace(Scene& scn);
     const rt_stats& stats() const { return last; }
+    void setDebug(bool on) { debug = on; }           // the DEBUG build's lines of rayTrace (src/raytrace.cpp:45-47, :78-82)
+    void setDetailedStats(bool on) { detailed = on; } // per-stage times and traversal work counts in stats()
+    int gpus() const { return ngpus; }
   private:
-    rt_ctx* ctx = nullptr;
+    std::vector<rt_ctx*> ctx;
     int accel = RT_ACCEL_AUTO;
+    int ngpus = 1;
+    bool debug = false, detailed = false;
     rt_stats last{};
 };
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 static_assert(RT_TILE == RT_TILE_PX, "tile size of the public header and the kernels differ");
@@ -65,6 +66,10 @@ struct rt_ctx {
     bool tuned = false, forced_modes = false;
     uint32_t tiles_cap = 0;    // batches of this scene that overflowed a pool that could not grow were split: keep to that size
     bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
+    bool stage_times = false;  // HIP events between the stage launches (rt_set_stage_times / RT_STAGE_TIMES)
+    rt_progress_fn progress = nullptr; void* progress_user = nullptr;
+    uint64_t grown_capacity = 0;   // pool size a single-tile batch needed beyond an explicit rt_options.pool_rays
+    RtkLaunchCache launch_cache{}; // resident-block counts of the traversal kernels on THIS device
     bool two_children = false;
     // Overlapped pipeline for thin batches: shadow + lighting of generation g run on a second stream while
     // the first traces generation g + 1.  The per-generation hit records and the hit list are double-buffered
@@ -104,6 +109,8 @@ struct rt_ctx {
 
     // staging
     uint8_t* d_rgb = nullptr; float* d_rgbf = nullptr; size_t rgb_pixels = 0; size_t rgbf_pixels = 0;
+    uint8_t* d_shard = nullptr; size_t shard_cap = 0;      // rt_render_multi: this context's shard
+    uint8_t* d_all = nullptr; size_t all_cap = 0;          // rt_render_multi, context 0: every shard
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -140,6 +147,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     if (opt) c->opt = *opt;
     for (int g = 0; g <= RT_MAX_GEN; g++) { c->mode_extend[g] = 3; c->mode_shadow[g] = 3; }
     if (const char* e = getenv("RT_COUNT_WORK")) c->count_work = atoi(e) != 0;
+    c->stage_times = getenv("RT_STAGE_TIMES") != nullptr;
     if (const char* e = getenv("RT_OVERLAP_RAYS")) c->overlap_rays = strtoull(e, nullptr, 10);
     if (const char* e = getenv("RT_PACKET_GENS")) {
         c->forced_modes = true;
@@ -175,6 +183,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     free_scene(c);
     free_pool(c);
     hipFree(c->d_counters); hipFree(c->d_tiles); hipFree(c->d_rowbase); hipFree(c->d_rgb); hipFree(c->d_rgbf);
+    hipFree(c->d_shard); hipFree(c->d_all);
     for (auto e : c->ev_scan) hipEventDestroy(e);
     for (auto e : c->ev_light) hipEventDestroy(e);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
@@ -229,8 +238,8 @@ static int upload(T** dst, const std::vector<T>& src, hipStream_t st) {
 
 static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
-extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
-    if (!c || !s) return RT_ERR_INVALID;
+extern "C" int rt_validate_scene(const rt_scene_desc* s) {
+    if (!s) return RT_ERR_INVALID;
     if (s->width <= 0 || s->height <= 0 || s->spp <= 0 || s->n_spheres < 0 || s->n_triangles < 0 ||
         s->n_lights < 0 || s->n_materials < 0) {
         rt_set_error("scene descriptor: non-positive film size / sample rate or negative count");
@@ -242,12 +251,28 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
         rt_set_error("scene descriptor: a count is positive but its array is NULL");
         return RT_ERR_INVALID;
     }
-    if (s->max_depth + 1 > RT_MAX_GEN) { rt_set_error("max_depth beyond the supported 63"); return RT_ERR_UNSUPPORTED; }
-    if ((uint64_t)s->width > 65535u * RT_TILE || (uint64_t)s->height > 65535u * RT_TILE) return RT_ERR_UNSUPPORTED;
+    if (s->max_depth >= RT_MAX_GEN) { rt_set_error("max_depth beyond the supported 63"); return RT_ERR_UNSUPPORTED; }
+    if ((uint64_t)s->width > 65535u * RT_TILE || (uint64_t)s->height > 65535u * RT_TILE) {
+        rt_set_error("film beyond 65535 tiles a side");
+        return RT_ERR_UNSUPPORTED;
+    }
+    // node and leaf offsets are 32-bit byte offsets of 64-byte records; a hit's record packs material << 2
+    if ((uint64_t)s->n_spheres + (uint64_t)s->n_triangles > (1ull << 26)) {
+        rt_set_error("more than 2^26 primitives");
+        return RT_ERR_UNSUPPORTED;
+    }
+    if ((uint64_t)s->n_materials >= (1ull << 29)) { rt_set_error("2^29 or more materials"); return RT_ERR_UNSUPPORTED; }
     for (int i = 0; i < s->n_spheres; i++)
         if (s->sphere_mat[i] < 0 || s->sphere_mat[i] >= s->n_materials) { rt_set_error("sphere material index out of range"); return RT_ERR_INVALID; }
     for (int i = 0; i < s->n_triangles; i++)
         if (s->tri_mat[i] < 0 || s->tri_mat[i] >= s->n_materials) { rt_set_error("triangle material index out of range"); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
+    if (!c || !s) return RT_ERR_INVALID;
+    int vrc = rt_validate_scene(s);
+    if (vrc != RT_OK) return vrc;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -317,7 +342,9 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     S.profile = getenv("RT_PROFILE") != nullptr;
     compute_camera(*s, c->cam);
 
-    int thr = c->opt.lbvh_threshold > 0 ? c->opt.lbvh_threshold : 64;
+    // brute force <-> LBVH: the caller's threshold, else the scene file's bvh_threshold (the switch the
+    // reference intended, src/raytrace.cpp:61-69, src/parse.cpp:252-256), else 64 primitives
+    int thr = c->opt.lbvh_threshold > 0 ? c->opt.lbvh_threshold : (s->bvh_threshold > 0 ? s->bvh_threshold : 64);
     int accel = c->opt.accel;
     if (accel == RT_ACCEL_AUTO) accel = (S.n_prims > thr) ? RT_ACCEL_LBVH : RT_ACCEL_BRUTE;
     // the LBVH is also built when brute force renders, if rt_query_rays may ask for it
@@ -340,6 +367,7 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     c->gen_rays_known = false;
     for (int g = 0; g <= RT_MAX_GEN; g++) c->gen_rays[g] = c->gen_rays_frame[g] = 0;
     c->tiles_cap = 0;
+    c->grown_capacity = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_scene = true;
     return RT_OK;
@@ -430,21 +458,51 @@ struct StageTimes {
     std::vector<hipEvent_t> ev;      // boundaries
     std::vector<int> cat;            // category of the span that ENDS at ev[i+1]
     hipStream_t st = nullptr;
+    StageTimes() = default;
+    StageTimes(const StageTimes&) = delete;
+    StageTimes& operator=(const StageTimes&) = delete;
+    ~StageTimes() { release(); }     // every exit path of the scheduler gives the events back
+    void release() {
+        for (auto e : ev) hipEventDestroy(e);
+        ev.clear(); cat.clear();
+    }
     void mark(int category) {
         if (!on) return;
-        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st);
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, st) != hipSuccess) {
+            // no stage times for this frame rather than times with a hole in them
+            if (e) hipEventDestroy(e);
+            (void)hipGetLastError();
+            on = false;
+            release();
+            return;
+        }
         ev.push_back(e); cat.push_back(category);
     }
     void collect(double out[4]) {
         if (!on) return;
         for (size_t i = 1; i < ev.size(); i++) {
-            float ms = 0; hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
             if (cat[i] >= 0) out[cat[i]] += ms;          // category -1: a wait for the other stream, nobody's time
         }
-        for (auto e : ev) hipEventDestroy(e);
-        ev.clear(); cat.clear();
+        release();
     }
 };
+
+// A launch that the runtime rejects (bad configuration, missing code object) is reported by the next
+// hipGetLastError, not by the launch: ask after every launch group and name the stage, so a failure does
+// not surface as an anonymous error at the final synchronisation.
+#define LAUNCH_CHECK(stage, g)                                                                        \
+    do {                                                                                              \
+        hipError_t e_ = hipGetLastError();                                                            \
+        if (e_ != hipSuccess) {                                                                       \
+            char b_[200];                                                                             \
+            std::snprintf(b_, sizeof(b_), "launch of %s (generation %d): %s", stage, g, hipGetErrorString(e_)); \
+            rt_set_error(b_);                                                                         \
+            return RT_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
 
 // What the overlapped pipeline needs beyond the pool: a second stream, one event pair per generation and
 // the second copy of the per-generation buffers.
@@ -486,6 +544,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1);
     tm.mark(3);
     if (S.max_depth < 0) rtk_fill_background(st, S, c->P, nsamples, c->max_blocks);   // nothing is traced at all
+    LAUNCH_CHECK("init", -1);
     uint64_t bound = nsamples;
     // The generations of the batch.  Fat ones run one after the other on the context's stream (A): extend ->
     // scan -> shadow -> shade.  From the first generation expected to be thin on (few rays: launches that last
@@ -522,15 +581,19 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         DPool P = c->P;
         if (any_ov && (g & 1)) { P.hp = c->hp2; P.hn = c->hn2; P.hd = c->hd2; P.hitlist = c->hitlist2; }
         if (ov && g - 2 >= first_ov) { hipStreamWaitEvent(st, c->ev_light[g - 2], 0); tm.mark(-1); }
-        rtk_extend(st, acc_e, S, P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work, ov);
+        rtk_extend(st, acc_e, S, P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work, c->launch_cache, ov);
+        LAUNCH_CHECK("extend", g);
         tm.mark(0);
         rtk_compact(st, P, c->d_counters, g, bound, c->max_blocks);
+        LAUNCH_CHECK("compact", g);
         tm.mark(3);
         const uint64_t items = bound * (uint64_t)std::max(1, S.nl);
         if (!ov) {
-            rtk_shadow(st, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work);
+            rtk_shadow(st, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work, c->launch_cache);
+            LAUNCH_CHECK("shadow", g);
             tm.mark(1);
             rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, 0);
+            LAUNCH_CHECK("shade", g);
             tm.mark(2);
         } else {
             hipEventRecord(c->ev_scan[g], st);
@@ -542,11 +605,12 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
             tmB.mark(-1);
             if (g >= 1) rtk_miss(B, S, P, c->d_counters, g, bound, c->max_blocks);
             tmB.mark(3);
-            rtk_shadow(B, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work);
+            rtk_shadow(B, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work, c->launch_cache);
             tmB.mark(1);
             rtk_shade(B, S, P, c->d_counters, g, bound, c->max_blocks, 2);
             tmB.mark(2);
             hipEventRecord(c->ev_light[g], B);
+            LAUNCH_CHECK("spawn / miss / shadow / light (two streams)", g);
         }
         bound = std::min<uint64_t>(bound * 2, cap);
     }
@@ -555,6 +619,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         rtk_resolve(st, S, c->P, c->d_counters, g, std::min<uint64_t>((uint64_t)nsamples << std::min(g, 20), cap), c->max_blocks);
     rtk_finish(st, c->cam, c->P, c->d_tiles, tile0, npixels, shard_mode, d_out, d_outf, c->max_blocks);
     if (c->count_work) rtk_reduce_stats(st, c->P, c->d_counters);
+    LAUNCH_CHECK("resolve / finish", -1);
     tm.mark(3);
     DCounters hc;
     HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
@@ -667,13 +732,14 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                 uint64_t bound = nsamples;
                 for (int g = 0; g < G; g++) {
                     hipEventRecord(ev[4 * g + 0], st);
-                    rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false);
+                    rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false, c->launch_cache);
                     hipEventRecord(ev[4 * g + 1], st);
                     rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
                     hipEventRecord(ev[4 * g + 2], st);
-                    rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false);
+                    rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false, c->launch_cache);
                     hipEventRecord(ev[4 * g + 3], st);
                     rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
+                    CAL_TRY(hipGetLastError());        // a rejected launch of this generation, named by the expression
                     bound = std::min<uint64_t>(bound * 2, c->P.capacity);
                 }
                 DCounters hc;
@@ -765,6 +831,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         uint64_t batch_samples = (uint64_t)tiles_per_batch * per_tile;
         uint64_t capacity = c->opt.pool_rays > 0 ? (uint64_t)c->opt.pool_rays : 4 * batch_samples;
         capacity = std::max(capacity, batch_samples);
+        capacity = std::max(capacity, c->grown_capacity);   // what a single tile turned out to need
         if (c->opt.pool_rays <= 0) capacity = std::max(capacity, c->pool_capacity);   // keep what earlier frames grew
         capacity = std::min<uint64_t>(capacity, 0x7FFFFFF0ull);
         rc = ensure_pool(c, capacity, batch_samples);
@@ -791,7 +858,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
 
     StageTimes tm;
     tm.st = c->stream;
-    tm.on = stats != nullptr && getenv("RT_STAGE_TIMES") != nullptr;
+    tm.on = stats != nullptr && c->stage_times;
     rt_stats acc{};
     double stage_b[4] = {0, 0, 0, 0};
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -803,6 +870,14 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
         work.push_back({t - n, n});
         t -= n;
     }
+    // progress in film pixels: tiles at the right and bottom edge are cut by the film
+    auto tile_pixels = [&](uint32_t t) {
+        const int tx = (int)(t & 0xFFFF), ty = (int)(t >> 16);
+        return (uint64_t)std::min(RT_TILE, c->cam.width - tx * RT_TILE) * (uint64_t)std::min(RT_TILE, c->cam.height - ty * RT_TILE);
+    };
+    uint64_t pixels_total = 0, pixels_done = 0;
+    for (uint32_t t : c->tiles) pixels_total += tile_pixels(t);
+    if (c->progress) c->progress(c->progress_user, 0, pixels_total);
     while (!work.empty()) {
         auto [t0, n] = work.back();
         work.pop_back();
@@ -813,14 +888,18 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
             acc.retries++;
             // Prefer a bigger pool (it stays for the following batches and frames) to a
             // smaller batch; split only when the device cannot hold a pool twice as big.
-            uint64_t bigger = c->pool_capacity * 2;
+            uint64_t bigger = (uint64_t)c->P.capacity * 2;      // twice what this batch ran with (the allocation may be larger)
             size_t free_b = 0, total_b = 0;
             // (an explicit rt_options.pool_rays is a hard cap: then batches are split)
             bool can_grow = c->opt.pool_rays <= 0 && bigger < 0xFFFFFFF0ull && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
                             (double)bigger * (140.0 + std::max(1, c->S.nl)) < 0.5 * ((double)free_b + (double)c->pool_capacity * 140.0);
             if (can_grow || n == 1) {
+                if (bigger > 0x7FFFFFF0ull) { rt_set_error("one tile needs a ray pool beyond 2^31 records"); return RT_ERR_UNSUPPORTED; }
                 rc = ensure_pool(c, bigger, c->scol_capacity);
                 if (rc != RT_OK) return rc;
+                // under an explicit pool_rays the next frame would start from the small pool again and overflow on
+                // the same tile: remember what it took
+                if (c->opt.pool_rays > 0) c->grown_capacity = std::max(c->grown_capacity, bigger);
                 try_overlap();
                 work.push_back({t0, n});
             } else {
@@ -832,6 +911,10 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
             continue;
         }
         acc.batches++;
+        if (c->progress) {
+            for (uint32_t t = t0; t < t0 + n; t++) pixels_done += tile_pixels(c->tiles[t]);
+            c->progress(c->progress_user, pixels_done, pixels_total);
+        }
         for (int k = 0; k < 4; k++) stage_b[k] += br.stage_b[k];
         acc.rays_secondary += br.secondary;
         acc.rays_shadow += br.shadow;
@@ -930,6 +1013,97 @@ extern "C" int rt_assemble_shards(rt_ctx* c, const void* d_all, int world, void*
     return RT_OK;
 }
 
+// ---------------------------------------------------------------- one process, several GPUs
+// Every context renders its shard on a host thread of its own (a context's calls are serialised by its owner;
+// the threads share nothing but the read-only arguments), then the shards travel to the first context's device.
+extern "C" int rt_render_multi(rt_ctx* const* ctxs, int n, uint8_t* rgb_out, rt_stats* stats) {
+    if (!ctxs || n <= 0 || !rgb_out) return RT_ERR_INVALID;
+    for (int r = 0; r < n; r++) {
+        if (!ctxs[r]) return RT_ERR_INVALID;
+        if (!ctxs[r]->has_scene) { rt_set_error("rt_load_scene has not succeeded on every context"); return RT_ERR_NO_SCENE; }
+        for (int q = 0; q < r; q++)
+            if (ctxs[q] == ctxs[r]) { rt_set_error("the same context given twice"); return RT_ERR_INVALID; }
+        if (ctxs[r]->cam.width != ctxs[0]->cam.width || ctxs[r]->cam.height != ctxs[0]->cam.height ||
+            ctxs[r]->cam.spp != ctxs[0]->cam.spp || ctxs[r]->S.n_prims != ctxs[0]->S.n_prims) {
+            rt_set_error("the contexts hold different scenes");
+            return RT_ERR_INVALID;
+        }
+    }
+    rt_ctx* c0 = ctxs[0];
+    const int w = c0->cam.width, h = c0->cam.height;
+    const size_t sb = rt_shard_bytes(w, h, n), px = (size_t)w * h;
+    for (int r = 0; r < n; r++) {
+        rt_ctx* c = ctxs[r];
+        HIP_TRY(hipSetDevice(c->device));
+        if (c->shard_cap < sb) {
+            hipFree(c->d_shard); c->d_shard = nullptr; c->shard_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_shard, sb));
+            c->shard_cap = sb;
+        }
+    }
+    HIP_TRY(hipSetDevice(c0->device));
+    if (c0->all_cap < sb * (size_t)n) {
+        hipFree(c0->d_all); c0->d_all = nullptr; c0->all_cap = 0;
+        HIP_TRY(hipMalloc(&c0->d_all, sb * (size_t)n));
+        c0->all_cap = sb * (size_t)n;
+    }
+    if (c0->rgb_pixels < px) {
+        hipFree(c0->d_rgb); c0->d_rgb = nullptr; c0->rgb_pixels = 0;
+        HIP_TRY(hipMalloc(&c0->d_rgb, px * 3));
+        c0->rgb_pixels = px;
+    }
+    std::vector<rt_stats> st((size_t)n);
+    std::vector<int> rcs((size_t)n, RT_OK);
+    std::vector<std::string> errs((size_t)n);
+    {
+        std::vector<std::thread> threads;
+        for (int r = 1; r < n; r++)
+            threads.emplace_back([&, r]() {
+                rcs[r] = rt_render_shard(ctxs[r], r, n, ctxs[r]->d_shard, &st[r]);
+                if (rcs[r] != RT_OK) errs[r] = rt_last_error();      // the message is per thread: carry it over
+            });
+        rcs[0] = rt_render_shard(c0, 0, n, c0->d_shard, &st[0]);
+        if (rcs[0] != RT_OK) errs[0] = rt_last_error();
+        for (auto& t : threads) t.join();
+    }
+    for (int r = 0; r < n; r++)
+        if (rcs[r] != RT_OK) {
+            rt_set_error("shard " + std::to_string(r) + " of " + std::to_string(n) + ": " + errs[r]);
+            return rcs[r];
+        }
+    // the one exchange step of the frame: every shard to the first device, each over its own link
+    HIP_TRY(hipSetDevice(c0->device));
+    for (int r = 0; r < n; r++) {
+        if (ctxs[r]->device == c0->device)
+            HIP_TRY(hipMemcpyAsync(c0->d_all + (size_t)r * sb, ctxs[r]->d_shard, sb, hipMemcpyDeviceToDevice, c0->stream));
+        else
+            HIP_TRY(hipMemcpyPeerAsync(c0->d_all + (size_t)r * sb, c0->device, ctxs[r]->d_shard, ctxs[r]->device, sb, c0->stream));
+    }
+    int rc = rt_assemble_shards(c0, c0->d_all, n, c0->d_rgb);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rgb_out, c0->d_rgb, px * 3, hipMemcpyDeviceToHost, c0->stream));
+    HIP_TRY(hipStreamSynchronize(c0->stream));
+    if (stats) {
+        rt_stats sum = st[0];
+        for (int r = 1; r < n; r++) {
+            sum.rays_primary += st[r].rays_primary; sum.rays_secondary += st[r].rays_secondary; sum.rays_shadow += st[r].rays_shadow;
+            for (int k = 0; k < 2; k++) {
+                sum.nodes_visited[k] += st[r].nodes_visited[k]; sum.sphere_tests[k] += st[r].sphere_tests[k];
+                sum.tri_tests[k] += st[r].tri_tests[k]; sum.lane_node_tests[k] += st[r].lane_node_tests[k];
+                sum.lane_prim_tests[k] += st[r].lane_prim_tests[k];
+            }
+            sum.ms_render = std::max(sum.ms_render, st[r].ms_render);
+            sum.ms_extend = std::max(sum.ms_extend, st[r].ms_extend); sum.ms_shadow = std::max(sum.ms_shadow, st[r].ms_shadow);
+            sum.ms_shade = std::max(sum.ms_shade, st[r].ms_shade); sum.ms_other = std::max(sum.ms_other, st[r].ms_other);
+            sum.launches_extend += st[r].launches_extend; sum.launches_shadow += st[r].launches_shadow;
+            sum.batches += st[r].batches; sum.retries += st[r].retries;
+            sum.generations = std::max(sum.generations, st[r].generations);
+        }
+        *stats = sum;
+    }
+    return RT_OK;
+}
+
 // ---------------------------------------------------------------- queries
 extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* d, const float* dmax,
                              int any_hit, int accel, int32_t* prim_out, float* dist2_out) {
@@ -972,6 +1146,19 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
 #undef Q_TRY
     cleanup();
     return rc;
+}
+
+extern "C" int rt_set_progress_callback(rt_ctx* c, rt_progress_fn fn, void* user) {
+    if (!c) return RT_ERR_INVALID;
+    c->progress = fn;
+    c->progress_user = user;
+    return RT_OK;
+}
+
+extern "C" int rt_set_stage_times(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_INVALID;
+    c->stage_times = on != 0;
+    return RT_OK;
 }
 
 extern "C" int rt_set_work_counters(rt_ctx* c, int on) {

@@ -5,16 +5,23 @@
 
 #include "rt_device.h"
 
+// Blocks of each traversal kernel that are resident at once on the context's device, by (counting variant,
+// walk): filled on first use from the occupancy query, kept per context because it is a property of the device.
+struct RtkLaunchCache {
+    int extend[2][5] = {{0}};
+    int shadow[2][5] = {{0}};
+};
+
 void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations);
 // generation 0 is generated on the fly from (cam, tiles, tile0); deeper generations read the pool
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
                 const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count,
-                bool defer_miss = false);
+                RtkLaunchCache& cache, bool defer_miss = false);
 // prefix sums over the wave masks of generation g: hit list, hit / next-generation counts, child offsets
 void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C);
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
-                uint64_t bound, int max_blocks, bool count);
+                uint64_t bound, int max_blocks, bool count, RtkLaunchCache& cache);
 // phase 0: lights + hand-over + spawn; 1: spawn only; 2: lights + hand-over only (overlapped pipeline)
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks,
                int phase = 0);

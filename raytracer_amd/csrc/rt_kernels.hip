@@ -1445,8 +1445,7 @@ static int resident_blocks(K kernel, int max_blocks) {
 
 template <bool COUNT>
 static void launch_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const GenSrc& G,
-                          int g, uint64_t bound, int max_blocks) {
-    static int res[5] = {0, 0, 0, 0, 0};
+                          int g, uint64_t bound, int max_blocks, int* res) {
     if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_extend<1, COUNT>, max_blocks)
                                  : accel == 2 ? resident_blocks(k_extend<2, COUNT>, max_blocks)
                                  : accel == 4 ? resident_blocks(k_extend<4, COUNT>, max_blocks)
@@ -1459,10 +1458,10 @@ static void launch_extend(hipStream_t st, int accel, const DScene& S, const DPoo
 }
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
                 const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count,
-                bool defer_miss) {
+                RtkLaunchCache& cache, bool defer_miss) {
     GenSrc G{cam, tiles, tile0, defer_miss ? 1 : 0};
-    if (count || S.profile) launch_extend<true>(st, accel, S, P, C, G, g, bound, max_blocks);
-    else launch_extend<false>(st, accel, S, P, C, G, g, bound, max_blocks);
+    if (count || S.profile) launch_extend<true>(st, accel, S, P, C, G, g, bound, max_blocks, cache.extend[1]);
+    else launch_extend<false>(st, accel, S, P, C, G, g, bound, max_blocks, cache.extend[0]);
 }
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {
     uint64_t groups = (bound + 63) / 64;
@@ -1474,8 +1473,7 @@ void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t b
 }
 template <bool COUNT>
 static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
-                          uint64_t bound, int max_blocks) {
-    static int res[5] = {0, 0, 0, 0, 0};
+                          uint64_t bound, int max_blocks, int* res) {
     if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_shadow<1, COUNT>, max_blocks)
                                  : accel == 2 ? resident_blocks(k_shadow<2, COUNT>, max_blocks)
                                  : accel == 4 ? resident_blocks(k_shadow<4, COUNT>, max_blocks)
@@ -1487,10 +1485,10 @@ static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPoo
     else hipLaunchKernelGGL((k_shadow<3, COUNT>), grid, block, 0, st, S, P, C, g);
 }
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
-                uint64_t bound, int max_blocks, bool count) {
+                uint64_t bound, int max_blocks, bool count, RtkLaunchCache& cache) {
     if (S.nl == 0) return;
-    if (count || S.profile) launch_shadow<true>(st, accel, S, P, C, g, bound, max_blocks);
-    else launch_shadow<false>(st, accel, S, P, C, g, bound, max_blocks);
+    if (count || S.profile) launch_shadow<true>(st, accel, S, P, C, g, bound, max_blocks, cache.shadow[1]);
+    else launch_shadow<false>(st, accel, S, P, C, g, bound, max_blocks, cache.shadow[0]);
 }
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                int max_blocks, int phase) {

@@ -238,8 +238,10 @@ extern "C" int rt_parse_scene_file(const char* path, int flags, rt_scene_desc** 
             }
             B->tri_flag.push_back(smooth ? 1 : 0);
             B->tri_mat.push_back(B->cur_mat);
-        } else if (tok == "bvh_threshold" || tok == "bvh_depth") {
-            (void)s.number_i();   // stored by the reference, never consulted by the brute-force path
+        } else if (tok == "bvh_threshold") {
+            B->d.bvh_threshold = s.number_i();   // src/parse.cpp:252-256; the AUTO switch between brute force and the LBVH
+        } else if (tok == "bvh_depth") {
+            B->d.bvh_depth = s.number_i();       // src/parse.cpp:257-261; carried, unused (no depth cap here)
         } else if (tok == "sample_rate") {
             B->d.spp = s.number_i();
         }

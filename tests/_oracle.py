@@ -9,6 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_oracle.so")
+REF_O0_SO = os.path.join(ROOT, "oracle", "_ref", "libref_oracle_O0.so")   # same sources, the flags the reference ships with (no -O)
 REFERENCE_TREE = "/root/reference"
 
 
@@ -95,6 +96,12 @@ class Oracle:
     def jitter_hash(self, seed, counter):
         return int(self.L.orc_jitter_hash(seed, counter))
 
+    def spot_branch_counts(self, reset=True):
+        """(alpha < angle1, alpha > angle2, interpolated): spot fall-off branches taken since the last reset"""
+        out = (C.c_ulonglong * 3)()
+        self.L.orc_spot_branch_counts(out, 1 if reset else 0)
+        return tuple(int(v) for v in out)
+
 
 def have_reference():
     return os.path.exists(REF_SO)
@@ -103,8 +110,8 @@ def have_reference():
 class Reference:
     """The unmodified reference, through oracle/ref_driver.cpp.  Holds ONE global scene."""
 
-    def __init__(self):
-        L = C.CDLL(REF_SO)
+    def __init__(self, path=REF_SO):
+        L = C.CDLL(path)
         L.ref_render.restype = C.c_double
         L.ref_render.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_output_name.restype = C.c_char_p
@@ -180,6 +187,22 @@ class Reference:
         out = np.zeros(7, np.float64)
         self.L.ref_camera_frame(_p(out))
         return out
+
+    def print_scene(self):
+        """The reference's printScene() of the loaded scene, captured from stdout -> str"""
+        import sys
+        import tempfile
+        sys.stdout.flush()
+        with tempfile.TemporaryFile() as tmp:
+            saved = os.dup(1)
+            try:
+                os.dup2(tmp.fileno(), 1)
+                self.L.ref_print_scene()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+            tmp.seek(0)
+            return tmp.read().decode(errors="replace")
 
     def write_bmp(self, path, rgb):
         rgb = np.ascontiguousarray(rgb, np.uint8)

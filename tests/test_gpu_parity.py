@@ -14,8 +14,15 @@ from conftest import bits, golden_cases, load_case, load_scene, same_float_image
 
 pytestmark = pytest.mark.gpu
 
-EXACT_FRACTION = 0.999      # pixels whose float colour must be bit-identical
+CONTRACT_FRACTION = 0.999   # the contract: pixels within 1 LSB per channel
+# Measured on MI355X: every comparison of this suite is bit-identical in float on EVERY pixel (device pow / acos
+# round like glibc on all inputs met so far), so that is what is demanded; a case that needs the contract's
+# slack must be listed here with its measured fraction.  The fractions of a run are written to
+# gpurun_out/parity_report.json.
+EXACT_FRACTION = 1.0        # pixels whose float colour must be bit-identical
 LSB_FRACTION = 1.0          # pixels whose RGB8 must be within 1 LSB
+LIBM_SLACK = {}             # what -> accepted bit-identical fraction (>= CONTRACT_FRACTION)
+REPORT = {}
 
 
 def crop(img, roi):
@@ -25,11 +32,29 @@ def crop(img, roi):
 
 def check_image(rgb, rgbf, gold_rgb, gold_rgbf, what):
     same = same_float_image(rgbf, gold_rgbf).all(axis=2)
-    frac = same.mean()
-    lsb = (np.abs(rgb.astype(np.int32) - gold_rgb.astype(np.int32)) <= 1).all(axis=2).mean()
+    frac = float(same.mean())
+    lsb = float((np.abs(rgb.astype(np.int32) - gold_rgb.astype(np.int32)) <= 1).all(axis=2).mean())
+    byte_same = float((rgb == gold_rgb).all(axis=2).mean())
+    REPORT[what] = {"pixels": int(same.size), "float_bit_identical": frac, "rgb8_identical": byte_same, "rgb8_within_1lsb": lsb}
+    need = max(CONTRACT_FRACTION, LIBM_SLACK.get(what, EXACT_FRACTION))
     assert lsb >= LSB_FRACTION, f"{what}: only {lsb:.6f} of pixels within 1 LSB"
-    assert frac >= EXACT_FRACTION, f"{what}: only {frac:.6f} of pixels bit-identical in float"
+    assert frac >= need, f"{what}: only {frac:.6f} of pixels bit-identical in float ({int(round((1 - frac) * same.size))} differ)"
     return frac
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _parity_report():
+    yield
+    import json
+    import os
+    from conftest import ROOT
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("accel", [ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH])
@@ -57,6 +82,51 @@ def test_larger_frames_against_live_oracle(oracle, tracer, name, w, h, spp):
     orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
     check_image(rgb, rgbf, orgb, orgbf, f"{name} vs live oracle")
     assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow)
+
+
+@pytest.mark.parametrize("accel", [ra.RT_ACCEL_BRUTE, ra.RT_ACCEL_LBVH])
+@pytest.mark.parametrize("w,h,spp", [(320, 240, 1), (256, 192, 4)])
+def test_spot_light_falloff_branches(oracle, accel, w, h, spp):
+    """Spot lights with angles in the range of acos(): the point-like, the zero and the interpolated branch
+    (src/raytrace.cpp:549-566) all run -- counted in the oracle -- and go through the device acos()."""
+    scene = load_scene("spot_falloff").copy(width=w, height=h, spp=spp, seed=9)
+    oracle.spot_branch_counts(reset=True)
+    orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
+    br = oracle.spot_branch_counts()
+    assert min(br) > 0.15 * sum(br), br
+    with ra.Tracer(accel=accel) as t:
+        t.load_scene(scene)
+        rgb, rgbf, st = t.render(want_float=True)
+    check_image(rgb, rgbf, orgb, orgbf, f"spot fall-off {w}x{h}x{spp} accel {accel}")
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow)
+
+
+def test_k2_full_size_frame_against_the_oracle(oracle, tracer):
+    """The second benchmark configuration at its stated size: outdoor + spot light, 1920x1080, 4 spp, the whole frame."""
+    scene = load_scene("outdoor_spot").copy(width=1920, height=1080, spp=4, seed=1)
+    tracer.load_scene(scene)
+    rgb, rgbf, st = tracer.render(want_float=True)
+    orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
+    check_image(rgb, rgbf, orgb, orgbf, "K2 1920x1080x4 whole frame")
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow)
+
+
+def test_k4_full_size_frame_against_the_oracle(oracle, tracer):
+    """The fourth benchmark configuration at its stated size: plant-h as normal_triangle, 660x512, max_depth 8.  The
+    oracle tests all 5 247 primitives per ray, so it renders three horizontal bands of the frame (a quarter of
+    it); the ray counts of the whole frame are pinned by brute force on the GPU."""
+    scene = load_scene("plant_h_smooth").copy(width=660, height=512, spp=1, max_depth=8, seed=1)
+    tracer.load_scene(scene)
+    rgb, rgbf, st = tracer.render(want_float=True)
+    assert st.accel_used == ra.RT_ACCEL_LBVH
+    for roi in [(0, 100, 660, 140), (0, 250, 660, 300), (0, 400, 660, 440)]:
+        orgb, orgbf, _, _ = oracle.render(scene, roi=roi, threads=16)
+        check_image(crop(rgb, roi), crop(rgbf, roi), orgb, orgbf, f"K4 660x512 depth 8, band {roi}")
+    with ra.Tracer(accel=ra.RT_ACCEL_BRUTE) as t:
+        t.load_scene(scene)
+        brgb, brgbf, bst = t.render(want_float=True)
+    assert np.array_equal(bits(brgbf), bits(rgbf)) and np.array_equal(brgb, rgb)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (bst.rays_primary, bst.rays_secondary, bst.rays_shadow)
 
 
 def test_k1_ray_count_pin(tracer):
@@ -299,9 +369,10 @@ def test_k3_full_size_frame_against_oracle_crops_and_across_partitions(oracle):
 
 
 def test_k5_full_scene_and_film_against_oracle_crops(oracle):
-    """The synthetic scene at full scale (10^6 spheres + 10^7 triangles) on the full 7680x4320 film.
-    The oracle tests every primitive for every ray (half a second per ray), so it renders two 4x4
-    crops at 2 samples per pixel; the GPU renders the shard (1 of 16) that holds each crop's tile."""
+    """The synthetic scene at full scale (10^6 spheres + 10^7 triangles) on the full 7680x4320 film, 2 spp.
+    The oracle tests every primitive for every ray (half a second per ray), so it renders four 4x4 crops --
+    centre and off-centre, all on geometry -- compared in float; the whole frame is also put together from
+    sixteen shards' worth of tiles for two of them, which must give the same bytes."""
     import torch
     from raytracer_amd import dist as rd
     from raytracer_amd.synth import synthetic_scene
@@ -310,18 +381,23 @@ def test_k5_full_scene_and_film_against_oracle_crops(oracle):
     world = 16
     with ra.Tracer() as t:
         t.load_scene(scene)
+        rgb, rgbf, st = t.render(want_float=True)
+        assert st.accel_used == ra.RT_ACCEL_LBVH and st.rays_shadow > 0 and st.rays_secondary > 0
+        seen_geometry = 0
+        for x0, y0 in [(3840, 2160), (3012, 1796), (4700, 2500), (2200, 2900)]:
+            roi = (x0, y0, x0 + 4, y0 + 4)
+            orgb, orgbf, cnt, _ = oracle.render(scene, roi=roi, threads=16)
+            seen_geometry += cnt.shadow > 0
+            check_image(crop(rgb, roi), crop(rgbf, roi), orgb, orgbf, f"K5 full scale 7680x4320x2, crop {roi}")
+        assert seen_geometry == 4, "the crops were meant to see geometry"
         buf = torch.zeros(ra.shard_bytes(scene.width, scene.height, world), dtype=torch.uint8, device="cuda:0")
         for x0, y0 in [(3840, 2160), (3012, 1796)]:
             tx, ty = x0 // ra.RT_TILE, y0 // ra.RT_TILE
             rank = next(r for r in range(world) if (tx, ty) in rd.tile_list(scene.width, scene.height, r, world))
-            st = t.render_shard(rank, world, buf.data_ptr())
-            assert st.accel_used == ra.RT_ACCEL_LBVH and st.rays_shadow > 0
+            t.render_shard(rank, world, buf.data_ptr())
             k = rd.tile_list(scene.width, scene.height, rank, world).index((tx, ty))
             tile = buf.cpu().numpy()[k * ra.RT_TILE * ra.RT_TILE * 3:(k + 1) * ra.RT_TILE * ra.RT_TILE * 3].reshape(ra.RT_TILE, ra.RT_TILE, 3)
-            px, py = x0 % ra.RT_TILE, y0 % ra.RT_TILE
-            orgb, _, cnt, _ = oracle.render(scene, roi=(x0, y0, x0 + 4, y0 + 4), threads=16)
-            assert cnt.shadow > 0, "the crop was meant to see geometry"
-            assert np.array_equal(tile[py:py + 4, px:px + 4], orgb), (x0, y0)
+            assert np.array_equal(tile, rgb[ty * ra.RT_TILE:(ty + 1) * ra.RT_TILE, tx * ra.RT_TILE:(tx + 1) * ra.RT_TILE]), (x0, y0)
 
 
 def test_coincident_primitives_and_tie_rules(oracle, monkeypatch):

@@ -172,3 +172,89 @@ def test_tile_partition_covers_the_film_once(w, h):
                 seen[ty, tx] += 1
         assert (seen == 1).all()
         assert ra.shard_bytes(w, h, world) == most * ra.RT_TILE * ra.RT_TILE * 3
+
+
+# ---------------------------------------------------------------- descriptor validation (no GPU needed)
+def test_descriptor_limits_are_rejected_on_the_host():
+    lib = api.load_library()
+    base = ra.SceneArrays()
+    assert ra.validate_scene(base) == api.RT_OK
+    assert ra.validate_scene(base.copy(max_depth=63)) == api.RT_OK
+    for depth in (64, 200, 2**31 - 1):          # INT_MAX used to overflow `max_depth + 1`
+        assert ra.validate_scene(base.copy(max_depth=depth)) == api.RT_ERR_UNSUPPORTED
+        assert b"max_depth" in lib.rt_last_error()
+    assert ra.validate_scene(base.copy(width=0)) == api.RT_ERR_INVALID
+    assert ra.validate_scene(base.copy(spp=0)) == api.RT_ERR_INVALID
+    assert ra.validate_scene(base.copy(width=65536 * 32)) == api.RT_ERR_UNSUPPORTED
+    # counts beyond what node offsets / hit records can address: only the counts are read before the rejection
+    d, keep = base.desc()
+    d.n_triangles = (1 << 26) + 1
+    d.tri_verts = d.tri_normals = d.tri_flags = d.tri_mat = 1      # non-NULL, never dereferenced
+    assert lib.rt_validate_scene(C.byref(d)) == api.RT_ERR_UNSUPPORTED and b"2^26" in lib.rt_last_error()
+    d, keep = base.desc()
+    d.n_materials = 1 << 29
+    assert lib.rt_validate_scene(C.byref(d)) == api.RT_ERR_UNSUPPORTED and b"materials" in lib.rt_last_error()
+    # a material index out of range
+    bad = base.copy(spheres=np.array([[0, 0, 3, 1]], np.float32), sphere_mat=np.array([5], np.int32))
+    assert ra.validate_scene(bad) == api.RT_ERR_INVALID
+
+
+def test_bvh_threshold_is_parsed_and_carried(tmp_path):
+    s = _parse_text(tmp_path, SCN + "bvh_threshold 123\n")
+    assert (s.bvh_threshold, s.bvh_depth) == (123, 7)
+    d, keep = s.desc()
+    assert (d.bvh_threshold, d.bvh_depth) == (123, 7)
+    assert _parse_text(tmp_path, "sphere 0 0 3 1\n").bvh_threshold == 0
+    p = tmp_path / "t.npz"
+    s.save(str(p))
+    assert ra.SceneArrays.load(str(p)).bvh_threshold == 123
+
+
+# ---------------------------------------------------------------- the command line, up to the point where a GPU is needed
+CLI = os.path.join(ROOT, "raytracer_amd", "raytrace")
+
+
+def _run_cli(args, cwd):
+    import subprocess
+    r = subprocess.run([CLI] + list(args), cwd=cwd, capture_output=True, text=True, timeout=120)
+    return r.returncode, r.stdout
+
+
+def test_cli_error_exits_match_the_reference(tmp_path):
+    # src/main.cpp:27-30: no argument -> message, exit(-1)
+    rc, out = _run_cli([], tmp_path)
+    assert rc == 255 and out == "No Scene File Specified\n"
+    # src/parse.cpp:96-99 + src/main.cpp:41-44
+    rc, out = _run_cli(["nothing_here.scn"], tmp_path)
+    assert rc == 255 and out == "File could not be opened: nothing_here.scn\nScene Parse Failed\n"
+    # src/parse.cpp:205-216: index checks name the vertex and the triangle being added
+    (tmp_path / "bad.scn").write_text("vertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\ntriangle 0 1 2\ntriangle 0 1 3\n")
+    rc, out = _run_cli(["bad.scn"], tmp_path)
+    assert rc == 255 and out == "Error: Specified vertex (3) in triangle (1) does not exist\nScene Parse Failed\n"
+    (tmp_path / "badn.scn").write_text("vertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nnormal 0 0 1\nnormal_triangle 0 1 2 0 0 1\n")
+    rc, out = _run_cli(["badn.scn"], tmp_path)
+    assert rc == 255 and out == "Error: Specified normal (1) in triangle (0) does not exist\nScene Parse Failed\n"
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference") and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_oracle.so"))),
+                    reason="reference build / tree not present")
+@pytest.mark.parametrize("rel", ["SphereExamples/spot_sphere.scn", "TriangleExamples/outdoor.scn", "ComplexExamples/test.scn"])
+def test_cli_debug_dump_equals_the_reference_printscene(tmp_path, rel):
+    """`--debug` prints what the reference's DEBUG build prints after parsing (src/main.cpp:50-53): compared
+    with the reference's own printScene() on the same file.  ComplexExamples/test.scn has
+    `film_resolution 1024 768`, which both must report as 1024 x 1024 (src/parse.cpp:119)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the trace would run: covered by the gpu suite")
+    from _oracle import Reference
+    path = os.path.join("/root/reference", rel)
+    ref = Reference()
+    assert ref.load(path) > 0
+    want = ref.print_scene()
+    rc, out = _run_cli([path, "--debug"], tmp_path)
+    assert rc == 255                       # no GPU here: the trace fails after the dump
+    head, _, rest = out.partition("Printing\n")
+    assert head.startswith("Scene parsed in ")
+    dump, _, tail = rest.partition("Beginning Trace\n")
+    assert dump == want
+    assert tail.endswith("Scene Trace Failed\n")

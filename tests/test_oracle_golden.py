@@ -53,3 +53,23 @@ def test_spheres1_full_frame_ray_count(oracle):
     rgb, _, cnt, _ = oracle.render(s, threads=8, want_float=False)
     assert (cnt.primary, cnt.secondary, cnt.shadow) == (307200, 1267376, 805513)
     assert tuple(rgb[0, 0]) == (12, 12, 12)
+
+
+def test_spot_falloff_known_answers_and_branch_coverage(oracle):
+    """Spot lights whose angles lie in the range of acos() (src/raytrace.cpp:549-566): colours of single
+    getColor calls (evaluateRayTree at depth == max_depth, whose children return the background untraced) and
+    of the full recursion along 96 primary rays, as the reference computed them; and the scene makes all
+    three branches of the fall-off run."""
+    import os
+    from conftest import GOLD
+    z = np.load(os.path.join(GOLD, "kat_spot.npz"), allow_pickle=False)
+    s = load_scene("spot_falloff")
+    oracle.spot_branch_counts(reset=True)
+    for i in range(len(z["o"])):
+        assert same_float_image(oracle.trace_ray(s, z["o"][i], z["d"][i], s.max_depth), z["col_leaf"][i]).all(), i
+        assert same_float_image(oracle.trace_ray(s, z["o"][i], z["d"][i], 0), z["col_full"][i]).all(), i
+    below_a1, above_a2, between = oracle.spot_branch_counts()
+    assert min(below_a1, above_a2, between) >= 40, (below_a1, above_a2, between)
+    oracle.render(s, threads=4)
+    br = oracle.spot_branch_counts()
+    assert min(br) > 0.15 * sum(br), br

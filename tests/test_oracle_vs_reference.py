@@ -73,3 +73,27 @@ def test_jittered_supersampling_matches(ref, oracle):
     _, rgbf_r, _ = ref.render(seed=5)
     _, rgbf_o, _, _ = oracle.render(scene)
     assert same_float_image(rgbf_r, rgbf_o).all()
+
+
+@pytest.mark.parametrize("w,h,spp", [(160, 120, 1), (200, 150, 4)])
+def test_spot_light_falloff_branches_match(ref, oracle, tmp_path, w, h, spp):
+    """src/raytrace.cpp:549-566 with angles in the range of acos(): all three branches run (counted in the
+    restatement) and the float image is bit-identical to the reference's."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_fixtures import SPOT_FALLOFF_SCN
+    p = tmp_path / "spot_falloff.scn"
+    p.write_text(SPOT_FALLOFF_SCN)
+    assert ref.load(str(p), w=w, h=h, spp=spp) > 0
+    scene = ref.scene_arrays(seed=3)
+    rgb_r, rgbf_r, _ = ref.render(seed=3)
+    oracle.spot_branch_counts(reset=True)
+    rgb_o, rgbf_o, cnt, _ = oracle.render(scene)
+    br = oracle.spot_branch_counts()
+    assert min(br) > 0.15 * sum(br), br
+    assert same_float_image(rgbf_r, rgbf_o).all() and np.array_equal(rgb_r, rgb_o)
+    assert cnt.shadow == 5 * (cnt.shadow // 5) and cnt.secondary > 0      # five lights per hit
+    # the product's parser reads the same file the same way (ref-compat film: W x W before the override)
+    b = ra.parse_scene_file(str(p), ref_compat=True)
+    assert np.array_equal(bits(b.lights), bits(scene.lights)) and (b.width, b.height) == (160, 160)
+    assert b.output_name == "spot_falloff.bmp.tail"

@@ -130,11 +130,91 @@ def smooth_normals(s: ra.SceneArrays) -> np.ndarray:
     return n.astype(np.float32)
 
 
+# Derived scene for the spot-light fall-off (src/raytrace.cpp:549-566).  The reference compares
+# acos(max(0, N.I)) -- radians, at most pi/2 -- with the file's raw angle values, so every shipped
+# spot light (45/90, 5/20) only ever takes the "acts like a point light" branch.  Angles in the
+# radian range make all three branches run: light 1 (0.35 / 0.9) mostly interpolates, light 2
+# (0.1 / 0.2) mostly contributes nothing, light 3 (45 / 90) is point-like, light 4 (0.6 / 1.3) mixes.
+SPOT_FALLOFF_SCN = """# spot lights whose angles lie in the range of acos()
+output_image spot_falloff.bmp.tail
+camera 0 4 -40 0 -0.05 1 0 1 0 20
+film_resolution 160 120
+background .1 .2 .4
+ambient_light .05 .05 .05
+max_depth 4
+material .2 .2 .2 .7 .6 .5 .3 .3 .3 20 0 0 0 1
+sphere -6 -2 8 4
+material 0 0 0 .3 .5 .7 .6 .6 .6 30 .8 .8 .8 1.4
+sphere 6 0 4 3.5
+material .1 .1 .1 .8 .8 .8 0 0 0 5 0 0 0 1
+vertex -60 -6 -30
+vertex 60 -6 -30
+vertex 60 -6 90
+vertex -60 -6 90
+triangle 0 1 2
+triangle 0 2 3
+vertex -30 -6 40
+vertex 30 -6 40
+vertex 0 30 45
+normal 0 0.2 -1
+normal 0.3 0 -1
+normal -0.3 0.1 -1
+material 0 0 0 .6 .7 .6 .2 .2 .2 8 0 0 0 1
+normal_triangle 4 5 6 0 1 2
+spot_light 900 900 800 0 25 -5 0 -1 0 0.35 0.9
+spot_light 400 100 100 -20 10 -10 1 -1 1 0.1 0.2
+spot_light 200 300 200 15 12 -15 0 0 1 45 90
+spot_light 500 500 100 0 2 20 0 -1 0 0.6 1.3
+point_light 50 50 80 10 20 0
+"""
+
+
+def spot_falloff_fixtures(R, O, tmpdir):
+    """scene, two reference renders and getColor known-answer rows for the spot fall-off branches"""
+    p = os.path.join(tmpdir, "spot_falloff.scn")
+    open(p, "w").write(SPOT_FALLOFF_SCN)
+    assert R.load(p, w=160, h=120) > 0
+    scene = R.scene_arrays()
+    scene.save(os.path.join(GOLD, "scenes", "spot_falloff.npz"))
+    for case, w, h, spp in (("spot_falloff", 160, 120, 1), ("spot_falloff_spp4", 128, 96, 4)):
+        s = scene.copy(width=w, height=h, spp=spp)
+        assert R.load(p, w=w, h=h, spp=spp) > 0
+        rgb, rgbf, secs = R.render(seed=1)
+        O.spot_branch_counts(reset=True)
+        orgb, orgbf, cnt, _ = O.render(s)
+        br = O.spot_branch_counts()
+        assert min(br) > 0.02 * sum(br), f"{case}: a fall-off branch is (nearly) unused: {br}"
+        assert np.array_equal(rgbf.view(np.uint32), orgbf.view(np.uint32)), f"{case}: restatement differs from reference"
+        np.savez_compressed(os.path.join(GOLD, f"render_{case}.npz"), scene=np.frombuffer(b"spot_falloff", np.uint8),
+                            params=np.array([w, h, spp, s.max_depth, s.proj, 1], np.int64),
+                            roi=np.array((0, 0, w, h), np.int64), rgb=rgb, rgbf=rgbf,
+                            counts=np.array([cnt.primary, cnt.secondary, cnt.shadow], np.uint64))
+        print("render", case, rgb.shape, "ref %.2fs" % secs, "rays", cnt.total, "spot branches (<a1, >a2, between)", br)
+    # getColor rows: evaluateRayTree at depth == max_depth is exactly one getColor call whose
+    # children return the background untraced (src/raytrace.cpp:132-135), and the full recursion.
+    assert R.load(p, w=160, h=120) > 0
+    rng = np.random.default_rng(17)
+    n = 96
+    xs = rng.integers(0, 160, n); ys = rng.integers(30, 120, n)
+    o = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32)
+    leaf = np.zeros((n, 3), np.float32); full = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        o[i], d[i] = R.get_ray(int(xs[i]), int(ys[i]), 0, seed=1)
+        leaf[i] = R.trace_ray(o[i], d[i], scene.max_depth)
+        full[i] = R.trace_ray(o[i], d[i], 0)
+    np.savez_compressed(os.path.join(GOLD, "kat_spot.npz"), xy=np.stack([xs, ys], 1).astype(np.int32), o=o, d=d,
+                        col_leaf=leaf, col_full=full)
+    print("kat_spot", n, "rows")
+
+
 def main():
     assert os.path.isdir(REFERENCE_TREE), "reference tree absent: fixtures can only be generated where it is mounted"
     os.makedirs(os.path.join(GOLD, "scenes"), exist_ok=True)
     R, O = Reference(), Oracle()
     tmpdir = tempfile.mkdtemp(prefix="rtfix")
+    spot_falloff_fixtures(R, O, tmpdir)
+    if "--only-spot" in sys.argv:      # leave the other (unchanged) fixture files as they are
+        return
     scenes, sources = {}, {}
     for name, rel in SCENES.items():
         sources[name] = os.path.join(REFERENCE_TREE, rel)
