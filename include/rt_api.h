@@ -202,6 +202,17 @@ int rt_assemble_shards(rt_ctx* ctx, const void* d_all, int world, void* d_rgb);
  * rt_render for every n. */
 int rt_render_multi(rt_ctx* const* ctxs, int n, uint8_t* rgb_out, rt_stats* stats);
 
+/* rt_assemble_shards for callers that must not allocate (HIP graph capture, serving loops,
+ * harnesses that forbid hipMalloc): no counterpart in the reference.  Same arguments, same
+ * result, but the tile-row table the kernel needs lives in a fixed array in device memory that the library
+ * holds per GPU (64 KiB) and is rebuilt by a small kernel on every call, so the call performs no
+ * hipMalloc / hipFree.  Limit: world * ceil(height / RT_TILE) <= RT_NOALLOC_MAX_ROWS, else
+ * RT_ERR_UNSUPPORTED.  The work is queued on the context's stream; the call waits for it
+ * unless that stream is being captured.  All contexts on one GPU share that GPU's array:
+ * calls that overlap in time on one GPU race. */
+#define RT_NOALLOC_MAX_ROWS 16384
+int rt_assemble_shards_noalloc(rt_ctx* ctx, const void* d_all, int world, void* d_rgb);
+
 /* -------------------------------------------------------- query utilities */
 /* Closest-hit / any-hit queries on caller-supplied rays (host pointers), used to
  * validate the LBVH against brute force.  o,d: [n][3].  dmax: [n] squared

@@ -109,6 +109,7 @@ def load_library():
         "rt_shard_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
         "rt_render_shard": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(RtStats)]),
         "rt_assemble_shards": (C.c_int, [vp, vp, C.c_int, vp]),
+        "rt_assemble_shards_noalloc": (C.c_int, [vp, vp, C.c_int, vp]),
         "rt_query_rays": (C.c_int, [vp, i64, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
         "rt_primary_rays": (C.c_int, [vp, i64, vp, vp, vp, vp, vp]),
         "rt_jitter_hash": (u32, [u32, u64]),
@@ -131,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "rt_render_device", "rt_shard_tiles", "rt_shard_bytes", "rt_render_shard", "rt_assemble_shards",
     "rt_query_rays", "rt_primary_rays", "rt_jitter_hash", "rt_parse_scene_file", "rt_free_scene",
     "rt_output_name", "rt_write_bmp24", "rt_set_work_counters", "rt_validate_scene", "rt_set_progress_callback",
-    "rt_set_stage_times", "rt_render_multi",
+    "rt_set_stage_times", "rt_render_multi", "rt_assemble_shards_noalloc",
 ]
 
 
@@ -398,6 +399,12 @@ class Tracer:
         rc = self._lib.rt_assemble_shards(self._ctx, d_all, world, d_rgb)
         if rc != RT_OK:
             raise RtError(rc, "rt_assemble_shards")
+
+    def assemble_shards_noalloc(self, d_all: int, world: int, d_rgb: int) -> None:
+        """rt_assemble_shards without any allocation (fixed per-GPU table; world * tile rows <= 16384)."""
+        rc = self._lib.rt_assemble_shards_noalloc(self._ctx, d_all, world, d_rgb)
+        if rc != RT_OK:
+            raise RtError(rc, "rt_assemble_shards_noalloc")
 
     def set_stage_times(self, on: bool):
         """Fill RtStats.ms_extend / ms_shadow / ms_shade / ms_other from the next render on."""

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -46,6 +47,36 @@ extern "C" const char* rt_strerror(int status) {
             return (e_ == hipErrorOutOfMemory) ? RT_ERR_NOMEM : RT_ERR_HIP;                   \
         }                                                                                     \
     } while (0)
+
+// ---------------------------------------------------------------- allocation-free scratch
+// The one buffer rt_assemble_shards_noalloc needs beyond its inputs and outputs: the tile-row table.  A
+// fixed array in device memory, one copy per GPU the library runs on (held until the process ends).  `scratch`
+// is only a host-side handle of the symbol: the array's address on a device comes from
+// hipGetSymbolAddress with that device current, is looked up once per device (rt_create) and is what every
+// kernel argument uses.
+static __device__ __align__(256) uint32_t scratch[RT_NOALLOC_MAX_ROWS];
+
+#define RT_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static uint32_t* g_scratch_ptr[RT_MAX_DEVICES];      // per device ordinal; nullptr = not looked up yet
+
+// Address of `scratch` on `device` (which must be the current device of the calling thread).
+static int scratch_on_device(int device, uint32_t** out) {
+    *out = nullptr;
+    if (device < 0 || device >= RT_MAX_DEVICES) { rt_set_error("device ordinal beyond the scratch table"); return RT_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        uint32_t* p = nullptr;
+        hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            rt_set_error(std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+            return RT_ERR_HIP;
+        }
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
 
 // ---------------------------------------------------------------- context
 struct rt_ctx {
@@ -106,6 +137,7 @@ struct rt_ctx {
     std::vector<uint32_t> tiles;
     uint32_t* d_tiles = nullptr;
     uint32_t* d_rowbase = nullptr; int rowbase_world = -1, rowbase_w = -1, rowbase_h = -1;
+    uint32_t* scratch = nullptr;    // this device's copy of the allocation-free scratch array (shared by all its contexts)
 
     // staging
     uint8_t* d_rgb = nullptr; float* d_rgbf = nullptr; size_t rgb_pixels = 0; size_t rgbf_pixels = 0;
@@ -169,6 +201,10 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     if (c->opt.stream) { c->stream = (hipStream_t)c->opt.stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIP_TRY(hipMalloc(&c->d_counters, sizeof(DCounters)));
+    {
+        int src = scratch_on_device(c->device, &c->scratch);     // the device is current here
+        if (src != RT_OK) return src;
+    }
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     guard.c = nullptr;
@@ -1010,6 +1046,33 @@ extern "C" int rt_assemble_shards(rt_ctx* c, const void* d_all, int world, void*
     rtk_assemble(c->stream, (const uint8_t*)d_all, rt_shard_bytes(w, h, world), world, w, h, ntx, nty, c->d_rowbase, (uint8_t*)d_rgb);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// The same de-interleave without any allocation: the table is rebuilt in this GPU's scratch array by a kernel
+// (every entry the assemble kernel reads is rewritten, so nothing of an earlier call survives), then the
+// assemble kernel reads it from there.  No hipMalloc / hipFree / host-to-device copy.
+extern "C" int rt_assemble_shards_noalloc(rt_ctx* c, const void* d_all, int world, void* d_rgb) {
+    if (!c || !d_all || !d_rgb || world <= 0) return RT_ERR_INVALID;
+    if (!c->has_scene) return RT_ERR_NO_SCENE;
+    const int w = c->cam.width, h = c->cam.height;
+    const int ntx = (w + RT_TILE - 1) / RT_TILE, nty = (h + RT_TILE - 1) / RT_TILE;
+    if ((uint64_t)world * (uint64_t)nty > (uint64_t)RT_NOALLOC_MAX_ROWS) {
+        char b[160];
+        std::snprintf(b, sizeof(b), "rt_assemble_shards_noalloc: %d ranks x %d tile rows exceed the %d entries of the fixed table",
+                      world, nty, RT_NOALLOC_MAX_ROWS);
+        rt_set_error(b);
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (!c->scratch) { rt_set_error("scratch array was not resolved on this device"); return RT_ERR_HIP; }
+    HIP_TRY(hipSetDevice(c->device));
+    rtk_rowbase(c->stream, world, ntx, nty, c->scratch);
+    rtk_assemble(c->stream, (const uint8_t*)d_all, rt_shard_bytes(w, h, world), world, w, h, ntx, nty, c->scratch, (uint8_t*)d_rgb);
+    HIP_TRY(hipGetLastError());
+    // a stream under graph capture must not be waited for; the captured work runs when the graph does
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs == hipStreamCaptureStatusNone) HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

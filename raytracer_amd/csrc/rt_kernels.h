@@ -34,6 +34,8 @@ void rtk_finish(hipStream_t st, const DCamera& cam, const DPool& P, const uint32
                 uint32_t npixels, int shard_mode, uint8_t* out, float* outf, int max_blocks);
 void rtk_assemble(hipStream_t st, const uint8_t* all, size_t shard_bytes, int world, int width, int height,
                   int ntx, int nty, const uint32_t* rowbase, uint8_t* out);
+// the tile-row table of rtk_assemble, written by a kernel into `rowbase` ([world * nty] uint32, device memory)
+void rtk_rowbase(hipStream_t st, int world, int ntx, int nty, uint32_t* rowbase);
 void rtk_query(hipStream_t st, int accel, int any_hit, const DScene& S, int64_t n, const float* o,
                const float* d, const float* dmax, int* prim_out, float* d2_out);
 void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* x, const int* y,

@@ -1396,6 +1396,19 @@ __global__ void k_assemble(const uint8_t* all, size_t shard_bytes, int world, in
     }
 }
 
+// rowbase[rank * nty + ty] of k_assemble, computed on the device (one thread per rank): tiles of tile row ty
+// that belong to `rank` are tx = first, first + world, ... with first = (rank - 3 ty) mod world.
+__global__ void k_rowbase(int world, int ntx, int nty, uint32_t* rowbase) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= world) return;
+    uint32_t acc = 0;
+    for (int ty = 0; ty < nty; ty++) {
+        rowbase[(size_t)r * nty + ty] = acc;
+        const int first = ((r - 3 * ty) % world + world) % world;
+        if (first < ntx) acc += (uint32_t)((ntx - first + world - 1) / world);
+    }
+}
+
 // ---------------------------------------------------------------- ray queries (validation)
 template <int ACCEL, bool ANY>
 __global__ __launch_bounds__(RT_BLOCK) void k_query(DScene S, int64_t n, const float* o, const float* d,
@@ -1520,6 +1533,9 @@ void rtk_assemble(hipStream_t st, const uint8_t* all, size_t shard_bytes, int wo
                   int ntx, int nty, const uint32_t* rowbase, uint8_t* out) {
     hipLaunchKernelGGL(k_assemble, dim3(grid_for((uint64_t)width * height, 4096)), dim3(RT_BLOCK), 0, st, all,
                        shard_bytes, world, width, height, ntx, nty, rowbase, out);
+}
+void rtk_rowbase(hipStream_t st, int world, int ntx, int nty, uint32_t* rowbase) {
+    hipLaunchKernelGGL(k_rowbase, dim3((unsigned)((world + 63) / 64)), dim3(64), 0, st, world, ntx, nty, rowbase);
 }
 void rtk_query(hipStream_t st, int accel, int any_hit, const DScene& S, int64_t n, const float* o,
                const float* d, const float* dmax, int* prim_out, float* d2_out) {
