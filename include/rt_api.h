@@ -136,6 +136,8 @@ typedef struct rt_stats {
     int32_t retries;           /* batches re-run at half size after a ray-pool overflow  */
     int32_t accel_used;        /* RT_ACCEL_BRUTE or RT_ACCEL_LBVH                        */
     int32_t generations;       /* deepest ray generation that held any ray, +1           */
+    double ms_host_enqueue;    /* host time spent queueing the frame's launches (wall clock,
+                                  before the wait for the device)                        */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

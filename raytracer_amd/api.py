@@ -66,7 +66,7 @@ class RtStats(C.Structure):
                 ("ms_shade", C.c_double), ("ms_other", C.c_double),
                 ("launches_extend", C.c_int32), ("launches_shadow", C.c_int32),
                 ("batches", C.c_int32), ("retries", C.c_int32), ("accel_used", C.c_int32),
-                ("generations", C.c_int32)]
+                ("generations", C.c_int32), ("ms_host_enqueue", C.c_double)]
 
     @property
     def rays(self) -> int:

@@ -8,6 +8,7 @@
 #include "rt_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -101,6 +102,7 @@ struct rt_ctx {
     rt_progress_fn progress = nullptr; void* progress_user = nullptr;
     uint64_t grown_capacity = 0;   // pool size a single-tile batch needed beyond an explicit rt_options.pool_rays
     RtkLaunchCache launch_cache{}; // resident-block counts of the traversal kernels on THIS device
+    std::vector<hipEvent_t> event_pool;   // timing events of the stage times, reused from frame to frame
     bool two_children = false;
     // Overlapped pipeline for thin batches: shadow + lighting of generation g run on a second stream while
     // the first traces generation g + 1.  The per-generation hit records and the hit list are double-buffered
@@ -156,8 +158,8 @@ static void free_scene(rt_ctx* c) {
 static void free_pool(rt_ctx* c) {
     hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.hd); hipFree(c->P.loc);
     hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.link); hipFree(c->P.wstats); hipFree(c->P.occl); hipFree(c->P.scol);
-    hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr); hipFree(c->P.hit_base);
-    hipFree(c->P.child_base); hipFree(c->P.blocksum); hipFree(c->P.hitlist); hipFree(c->P.wq);
+    hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr);
+    hipFree(c->P.child_base); hipFree(c->P.scan_state); hipFree(c->P.hitlist); hipFree(c->P.wq);
     hipFree(c->hp2); hipFree(c->hn2); hipFree(c->hd2); hipFree(c->hitlist2);
     c->hp2 = c->hn2 = c->hd2 = nullptr; c->hitlist2 = nullptr; c->alt_capacity = 0;
     c->P = DPool{};
@@ -220,6 +222,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     free_pool(c);
     hipFree(c->d_counters); hipFree(c->d_tiles); hipFree(c->d_rowbase); hipFree(c->d_rgb); hipFree(c->d_rgbf);
     hipFree(c->d_shard); hipFree(c->d_all);
+    for (auto e : c->event_pool) hipEventDestroy(e);
     for (auto e : c->ev_scan) hipEventDestroy(e);
     for (auto e : c->ev_light) hipEventDestroy(e);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
@@ -388,8 +391,13 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
         int radius = 16;                                     // RT_PLOC_RADIUS=0: Karras hierarchy only
         if (const char* e = getenv("RT_PLOC_RADIUS")) radius = std::max(0, std::min(256, atoi(e)));
         int depth_k = 0;
+        // 4-wide nodes with float boxes (128 B) while the tree fits the L2 caches (32 MB of them at 2^19 primitives):
+        // there a walk's step is latency-bound and decoding bytes only lengthens it (K4: 2.2 ms against 2.4); beyond,
+        // with 8-bit boxes (64 B): the walks are bound by the bytes they move (K5: 68 ms against 73)
+        S.wide_quant = S.n_prims > (1 << 19) ? 1 : 0;
+        if (const char* e = getenv("RT_WIDE_QUANT")) S.wide_quant = atoi(e) != 0;
         hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf,
-                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt, &c->d_wide, &c->d_wide_alt);
+                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt, &c->d_wide, &c->d_wide_alt, S.wide_quant);
         if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
         S.nodes = c->d_nodes; S.nodes4 = c->d_wide; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = 0; S.depth = depth_k;
         if (getenv("RT_VERBOSE"))
@@ -467,9 +475,10 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.mask_hit, groups * 8));
     HIP_TRY(hipMalloc(&c->P.mask_refl, groups * 8));
     HIP_TRY(hipMalloc(&c->P.mask_refr, groups * 8));
-    HIP_TRY(hipMalloc(&c->P.hit_base, groups * 4));
     HIP_TRY(hipMalloc(&c->P.child_base, groups * 4));
-    HIP_TRY(hipMalloc(&c->P.blocksum, sblocks * sizeof(uint2)));
+    c->P.scan_words = sblocks + RT_MAX_GEN + 8;       // generation g starts at word (groups before it >> 8) + g
+    HIP_TRY(hipMalloc(&c->P.scan_state, c->P.scan_words * sizeof(unsigned long long) + (RT_MAX_GEN + 1) * sizeof(uint32_t)));
+    c->P.scan_ticket = (uint32_t*)(c->P.scan_state + c->P.scan_words);
     HIP_TRY(hipMalloc(&c->P.hitlist, capacity * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->P.occl, occl));
     HIP_TRY(hipMalloc(&c->P.scol, samples * sizeof(float4)));
@@ -487,6 +496,7 @@ struct BatchResult {
     uint64_t secondary = 0, shadow = 0, nodes[2] = {0, 0}, sph[2] = {0, 0}, tri[2] = {0, 0}, lane_nodes[2] = {0, 0}, lane_prims[2] = {0, 0};
     int generations = 0;
     double stage_b[4] = {0, 0, 0, 0};      // stage times of the second stream (overlapped pipeline)
+    double host_enqueue_ms = 0;            // wall time of queueing the launches
 };
 
 struct StageTimes {
@@ -494,18 +504,23 @@ struct StageTimes {
     std::vector<hipEvent_t> ev;      // boundaries
     std::vector<int> cat;            // category of the span that ENDS at ev[i+1]
     hipStream_t st = nullptr;
+    std::vector<hipEvent_t>* pool = nullptr;   // the context's spare events: creating one costs microseconds, a frame uses dozens
     StageTimes() = default;
     StageTimes(const StageTimes&) = delete;
     StageTimes& operator=(const StageTimes&) = delete;
     ~StageTimes() { release(); }     // every exit path of the scheduler gives the events back
     void release() {
-        for (auto e : ev) hipEventDestroy(e);
+        for (auto e : ev) {
+            if (pool) pool->push_back(e);
+            else hipEventDestroy(e);
+        }
         ev.clear(); cat.clear();
     }
     void mark(int category) {
         if (!on) return;
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, st) != hipSuccess) {
+        if (pool && !pool->empty()) { e = pool->back(); pool->pop_back(); }
+        if ((!e && hipEventCreate(&e) != hipSuccess) || hipEventRecord(e, st) != hipSuccess) {
             // no stage times for this frame rather than times with a hole in them
             if (e) hipEventDestroy(e);
             (void)hipGetLastError();
@@ -576,6 +591,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     const uint32_t nsamples = (uint32_t)nsamples64;
     hipStream_t st = c->stream;
     const uint64_t cap = c->P.capacity;
+    const auto host_t0 = std::chrono::steady_clock::now();
     tm.mark(3);
     rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1);
     tm.mark(3);
@@ -606,7 +622,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     }
     hipStream_t B = c->stream2;
     StageTimes tmB;
-    tmB.st = B; tmB.on = tm.on && any_ov;
+    tmB.st = B; tmB.on = tm.on && any_ov; tmB.pool = &c->event_pool;
     for (int g = 0; g <= S.max_depth; g++) {
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
@@ -658,6 +674,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     LAUNCH_CHECK("resolve / finish", -1);
     tm.mark(3);
     DCounters hc;
+    res.host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     res.overflow = hc.overflow != 0;
@@ -894,6 +911,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
 
     StageTimes tm;
     tm.st = c->stream;
+    tm.pool = &c->event_pool;
     tm.on = stats != nullptr && c->stage_times;
     rt_stats acc{};
     double stage_b[4] = {0, 0, 0, 0};
@@ -947,6 +965,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
             continue;
         }
         acc.batches++;
+        acc.ms_host_enqueue += br.host_enqueue_ms;
         if (c->progress) {
             for (uint32_t t = t0; t < t0 + n; t++) pixels_done += tile_pixels(c->tiles[t]);
             c->progress(c->progress_user, pixels_done, pixels_total);
@@ -1161,6 +1180,7 @@ extern "C" int rt_render_multi(rt_ctx* const* ctxs, int n, uint8_t* rgb_out, rt_
             sum.launches_extend += st[r].launches_extend; sum.launches_shadow += st[r].launches_shadow;
             sum.batches += st[r].batches; sum.retries += st[r].retries;
             sum.generations = std::max(sum.generations, st[r].generations);
+            sum.ms_host_enqueue = std::max(sum.ms_host_enqueue, st[r].ms_host_enqueue);
         }
         *stats = sum;
     }

@@ -84,7 +84,9 @@ struct DScene {
     F3 bg, ambient;
     // LBVH (valid when nodes != nullptr)
     const float4* nodes;     // [n_internal][4], see rt_lbvh.hip
-    const float4* nodes4;    // 4-wide collapse of the same tree, [..][8] (nullptr if not built); root = node 0 in both
+    const float4* nodes4;    // 4-wide collapse of the same tree (nullptr if not built); root = node 0 in both.  wide_quant != 0:
+                             // one 64-byte record [4] per node with 8-bit child boxes; else [8] with float boxes
+    int wide_quant;
     const int* prim_idx;     // [ns+nt] sorted primitive ids (sphere i, or ns + triangle i)
     const float4* leaf;      // [ns+nt][3] primitive records in tree order, see rt_lbvh.hip
     int root;                // root reference
@@ -127,9 +129,12 @@ struct DPool {
     unsigned long long* mask_refl;   // hit spawns a reflection ray
     unsigned long long* mask_refr;   // hit spawns a refraction ray
     // ... and their prefix sums, for the current generation only (index = group)
-    uint32_t* hit_base;    // hits before the group
     uint32_t* child_base;  // next-generation rays before the group
-    uint2* blocksum;       // scan scratch: per 256 groups (hits, children)
+    // single-pass scan: one state word per 256 groups of every generation of the batch (zeroed per batch), and
+    // a block ticket per generation; scan_ticket lies right behind the scan_words state words (one allocation)
+    unsigned long long* scan_state;
+    uint32_t* scan_ticket;
+    uint64_t scan_words;
     uint32_t* hitlist;     // compacted: h -> ray index within the generation, in ray order
     uint8_t* occl;    // [h * nl + light] 1 = in shadow
     float4* scol;     // per sample colour of the batch

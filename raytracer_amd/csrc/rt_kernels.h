@@ -46,4 +46,4 @@ void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* 
 // and *leaf ([n_prims][3] float4, primitives in tree order) with hipMalloc; returns a hipError_t as int.  n_prims >= 2.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes,
               int** prim_idx, float4** leaf, int* depth, int ploc_radius, float4** ploc_nodes, int* ploc_depth,
-              float4** wide_nodes, float4** ploc_wide_nodes);
+              float4** wide_nodes, float4** ploc_wide_nodes, int wide_quantised);

@@ -302,8 +302,9 @@ __device__ __forceinline__ void order2(float& ka, int& ra, float& kb, int& rb) {
 template <bool WIDE>
 __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const SlabRay& R, float tmax, int* stack,
                                                int& sp, TraceStats& ts) {
-    // counted in 64-byte records / box pairs: a wide node is two of each
-    ts.nodes += WIDE ? 2 : 1; ts.lane_nodes += WIDE ? 2 : 1;
+    // counted in 64-byte records fetched and box pairs tested: a wide node is two pairs, and one record when its
+    // boxes are quantised, two when they are floats
+    ts.nodes += (WIDE && !S.wide_quant) ? 2 : 1; ts.lane_nodes += WIDE ? 2 : 1;
     if (!WIDE) {
         const v4f* nd = (const v4f*)S.nodes + 4 * (size_t)cur;
         v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
@@ -320,13 +321,39 @@ __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const S
         if (h1) return c1;
         return sp > 0 ? stack[--sp] : LANE_DONE;
     } else {
-        const v4f* nd = (const v4f*)S.nodes4 + 8 * (size_t)cur;
-        v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
         float k0, k1, k2, k3;
         bool h0, h1, h2, h3;
-        box_pair<8>(q0, q1, q2, R, tmax, h0, h1, k0, k1);
-        box_pair<8>(q3, q4, q5, R, tmax, h2, h3, k2, k3);
-        int r0 = (int)fbits(q6.x), r1 = (int)fbits(q6.y), r2 = (int)fbits(q6.z), r3 = (int)fbits(q6.w);
+        int r0, r1, r2, r3;
+        if (S.wide_quant) {
+            // one 64-byte record: origin + step exponents, the child boxes as bytes on that grid, four references
+            const v4f* nd = (const v4f*)S.nodes4 + 4 * (size_t)cur;
+            const v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            const uint32_t eb = fbits(q0.w);
+            // plane distance t = (origin + q * step) * inv - o * inv = q * (step * inv) + (origin * inv + noi)
+            const float ax = bitsf((eb & 0xFFu) << 23) * R.inv.x, ay = bitsf(((eb >> 8) & 0xFFu) << 23) * R.inv.y,
+                        az = bitsf(((eb >> 16) & 0xFFu) << 23) * R.inv.z;
+            const float bx = __builtin_fmaf(q0.x, R.inv.x, R.noi.x), by = __builtin_fmaf(q0.y, R.inv.y, R.noi.y),
+                        bz = __builtin_fmaf(q0.z, R.inv.z, R.noi.z);
+            const uint32_t lx = fbits(q1.x), ly = fbits(q1.y), lz = fbits(q1.z), hx = fbits(q1.w), hy = fbits(q2.x), hz = fbits(q2.y);
+            float kk[4]; bool hh[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float tlx = __builtin_fmaf((float)((lx >> (8 * c)) & 0xFFu), ax, bx), thx = __builtin_fmaf((float)((hx >> (8 * c)) & 0xFFu), ax, bx);
+                const float tly = __builtin_fmaf((float)((ly >> (8 * c)) & 0xFFu), ay, by), thy = __builtin_fmaf((float)((hy >> (8 * c)) & 0xFFu), ay, by);
+                const float tlz = __builtin_fmaf((float)((lz >> (8 * c)) & 0xFFu), az, bz), thz = __builtin_fmaf((float)((hz >> (8 * c)) & 0xFFu), az, bz);
+                hh[c] = slab_hit<8>((v2f){tlx, thx}, (v2f){tly, thy}, (v2f){tlz, thz}, tmax, kk[c]);
+            }
+            k0 = kk[0]; k1 = kk[1]; k2 = kk[2]; k3 = kk[3];
+            h0 = hh[0]; h1 = hh[1]; h2 = hh[2]; h3 = hh[3];
+            r0 = (int)fbits(q2.z); r1 = (int)fbits(q2.w); r2 = (int)fbits(q3.x); r3 = (int)fbits(q3.y);
+        } else {
+            // 128 bytes: four float boxes, then the four references
+            const v4f* nd = (const v4f*)S.nodes4 + 8 * (size_t)cur;
+            v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
+            box_pair<8>(q0, q1, q2, R, tmax, h0, h1, k0, k1);
+            box_pair<8>(q3, q4, q5, R, tmax, h2, h3, k2, k3);
+            r0 = (int)fbits(q6.x); r1 = (int)fbits(q6.y); r2 = (int)fbits(q6.z); r3 = (int)fbits(q6.w);
+        }
         const float inf = __builtin_inff();
         // a missed or empty slot sorts last (an empty slot's inverted box reads as an infinite slab in the min / max test)
         k0 = (h0 && r0 != LANE_DONE) ? k0 : inf; k1 = (h1 && r1 != LANE_DONE) ? k1 : inf;
@@ -934,15 +961,25 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
 }
 
 // ---------------------------------------------------------------- queue compaction (prefix sums)
-// One thread per 64-ray group.  scan1: per-block sums of (hits, children);
-// scan2: one block turns the block sums into exclusive prefixes and publishes the
-// generation totals; scan3: per-group bases + the compacted hit list.
+// One thread per 64-ray group, ONE launch per generation: a single-pass scan with decoupled look-back
+// (Merrill & Garland 2016).  A block takes the next 256 groups by ticket (so every block with a smaller
+// number is already running and nobody waits for a block that has not started), scans its (hits, children)
+// counts in LDS, publishes its total, and its first wave then reads the totals of the blocks before it --
+// 64 at a time -- back to the nearest one that has published its inclusive prefix.  With the prefix the block
+// writes the child offsets of its groups and its part of the compacted hit list; the last block publishes
+// the generation totals.  No atomics on the ray data, hits and children stay in ray order.
+// Everything one block tells another travels INSIDE the state word (flag + both sums in 64 bits), so the
+// words are read and written with relaxed device-scope atomics and no fence: a release / acquire pair at
+// device scope would write back and invalidate the whole L2 of the XCD on every publication.
+// (Three launches -- block sums, scan of the sums, offsets -- took 45 us per generation on a thin frame, most
+// of it between the launches; this is one.)
 #define SCAN_BLOCK 256
+#define SCAN_AGG 1ull        // state word = flag << 62 | hits << 31 | children (children saturate at 2^31 - 1:
+#define SCAN_PREFIX 2ull     // more than any pool holds, so a saturated sum always raises the overflow flag)
+#define SCAN_KIDS_MAX 0x7FFFFFFFull
 
-__device__ __forceinline__ uint2 group_counts(const DPool& P, uint32_t gbase, uint32_t grp, uint32_t ngroups) {
-    if (grp >= ngroups) return make_uint2(0, 0);
-    return make_uint2((uint32_t)__popcll(P.mask_hit[gbase + grp]),
-                      (uint32_t)(__popcll(P.mask_refl[gbase + grp]) + __popcll(P.mask_refr[gbase + grp])));
+__device__ __forceinline__ unsigned long long scan_pack(unsigned long long flag, uint32_t hits, unsigned long long kids) {
+    return (flag << 62) | ((unsigned long long)hits << 31) | (kids > SCAN_KIDS_MAX ? SCAN_KIDS_MAX : kids);
 }
 
 // block-wide exclusive scan of a uint2 (both components), returns the block total
@@ -963,73 +1000,118 @@ __device__ __forceinline__ uint2 block_scan(uint2 v, uint2* lds /*[SCAN_BLOCK]*/
     return make_uint2(incl.x - v.x, incl.y - v.y);
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan1(DPool P, DCounters* C, int g) {
-    __shared__ uint2 lds[SCAN_BLOCK];
-    if (C->overflow) return;
-    const uint32_t start = gen_start(C, g);
-    const uint32_t count = gen_size(C, g, start, P.capacity);
-    const uint32_t ngroups = (count + 63) >> 6;
-    const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        uint2 v = group_counts(P, C->gbase[g], b * SCAN_BLOCK + threadIdx.x, ngroups), total;
-        block_scan(v, lds, total);
-        if (threadIdx.x == 0) P.blocksum[b] = total;
-    }
-}
+// A block's tile is 256 x items groups, items = 1 .. 8 chosen per generation: thin generations get many small
+// tiles (parallelism; their launch is over when the last tile is), fat ones few large tiles (the look-back of
+// thousands of tiles that run at once would walk through thousands of unfinished neighbours).
+#define SCAN_ITEMS 8                                  // most groups per thread
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)           // most groups per block and state word: 2048 = 131072 rays
+#define SCAN_TILES_WANTED 1024u
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan2(DPool P, DCounters* C, int g) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(DPool P, DCounters* C, int g) {
     __shared__ uint2 lds[SCAN_BLOCK];
+    __shared__ uint32_t hb[SCAN_TILE];
+    __shared__ unsigned long long hm[SCAN_TILE];
+    __shared__ uint32_t s_bid;
+    __shared__ unsigned long long s_prefix[2];        // hits, children before this block
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
     const uint32_t ngroups = (count + 63) >> 6;
-    const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    uint2 carry = make_uint2(0, 0);
-    for (uint32_t base = 0; base < nblocks; base += SCAN_BLOCK) {
-        uint32_t b = base + threadIdx.x;
-        uint2 v = (b < nblocks) ? P.blocksum[b] : make_uint2(0, 0), total;
-        uint2 ex = block_scan(v, lds, total);
-        if (b < nblocks) P.blocksum[b] = make_uint2(carry.x + ex.x, carry.y + ex.y);
-        carry = make_uint2(carry.x + total.x, carry.y + total.y);
-    }
-    if (threadIdx.x == 0) {
-        C->hit_count[g] = carry.x;
-        C->gen_count[g + 1] = carry.y;
-        C->gbase[g + 1] = C->gbase[g] + ngroups;
-        if ((uint64_t)start + C->gen_count[g] + carry.y > (uint64_t)P.capacity) C->overflow = 1;
-    }
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan3(DPool P, DCounters* C, int g) {
-    __shared__ uint2 lds[SCAN_BLOCK];
-    __shared__ uint32_t hb[SCAN_BLOCK];
-    __shared__ unsigned long long hm[SCAN_BLOCK];
-    if (C->overflow) return;
-    const uint32_t start = gen_start(C, g);
-    const uint32_t count = gen_size(C, g, start, P.capacity);
-    const uint32_t ngroups = (count + 63) >> 6;
-    const uint32_t nblocks = (ngroups + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        uint32_t grp = b * SCAN_BLOCK + threadIdx.x;
-        uint2 v = group_counts(P, C->gbase[g], grp, ngroups), total;
-        uint2 ex = block_scan(v, lds, total);
-        uint2 bs = P.blocksum[b];
-        uint32_t hbase = bs.x + ex.x;
-        if (grp < ngroups) {
-            P.hit_base[grp] = hbase;
-            P.child_base[grp] = bs.y + ex.y;
-        }
-        hb[threadIdx.x] = hbase;
-        hm[threadIdx.x] = (grp < ngroups) ? P.mask_hit[C->gbase[g] + grp] : 0ull;
+    uint32_t items = (ngroups + SCAN_BLOCK * SCAN_TILES_WANTED - 1) / (SCAN_BLOCK * SCAN_TILES_WANTED);
+    items = items < 1u ? 1u : (items > (uint32_t)SCAN_ITEMS ? (uint32_t)SCAN_ITEMS : items);
+    const uint32_t tile = SCAN_BLOCK * items;
+    const uint32_t nblocks = ngroups ? (ngroups + tile - 1) / tile : 1;   // an empty generation still publishes its totals
+    // the grid is sized for the most rays the generation could hold: blocks beyond the tiles there are leave at once
+    // (a ticket each would queue thousands of atomics on one counter); the others share the tiles by ticket
+    if (blockIdx.x >= nblocks) return;
+    const uint32_t gbase = C->gbase[g];
+    // this generation's state words: generations never share one (gbase counts the groups before it)
+    unsigned long long* state = P.scan_state + (gbase >> 8) + (uint32_t)g;
+    const uint32_t lane = threadIdx.x & 63u;
+    while (true) {
+        if (threadIdx.x == 0) s_bid = atomicAdd(&P.scan_ticket[g], 1u);
         __syncthreads();
-        // compacted hit list of the block's 256 groups: one thread per ray, coalesced
-        for (uint32_t k = threadIdx.x; k < SCAN_BLOCK * 64u; k += SCAN_BLOCK) {
-            uint32_t gl = k >> 6, bit = k & 63u;
-            unsigned long long m = hm[gl];
+        const uint32_t bid = s_bid;
+        if (bid >= nblocks) break;
+        const uint32_t first = bid * tile;                                          // first group of the block
+        const uint32_t ng = ngroups > first ? min(tile, ngroups - first) : 0u;
+        // thread t owns groups first + t * items .. + items - 1; the masks go to LDS through coalesced loads
+        for (uint32_t k = threadIdx.x; k < tile; k += SCAN_BLOCK) {
+            unsigned long long mh = 0ull;
+            uint32_t kids = 0;
+            if (k < ng) {
+                mh = P.mask_hit[gbase + first + k];
+                kids = (uint32_t)(__popcll(P.mask_refl[gbase + first + k]) + __popcll(P.mask_refr[gbase + first + k]));
+            }
+            hm[k] = mh;
+            hb[k] = kids;
+        }
+        __syncthreads();
+        uint32_t eh[SCAN_ITEMS], ek[SCAN_ITEMS];
+        uint2 v = make_uint2(0, 0);
+#pragma unroll
+        for (int q = 0; q < SCAN_ITEMS; q++) {
+            eh[q] = v.x; ek[q] = v.y;
+            if ((uint32_t)q < items) {
+                const uint32_t k = threadIdx.x * items + q;
+                v.x += (uint32_t)__popcll(hm[k]); v.y += hb[k];
+            }
+        }
+        uint2 total;
+        const uint2 ex = block_scan(v, lds, total);
+        if (threadIdx.x < 64) {                    // wave 0: publish, look back
+            unsigned long long ph = 0ull, pk = 0ull;
+            if (bid == 0) {
+                if (lane == 0) __hip_atomic_store(&state[0], scan_pack(SCAN_PREFIX, total.x, total.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane == 0) __hip_atomic_store(&state[bid], scan_pack(SCAN_AGG, total.x, total.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int top = (int)bid - 1;            // nearest block not yet added
+                while (true) {
+                    const int j = top - (int)lane;
+                    unsigned long long sw = scan_pack(SCAN_PREFIX, 0, 0);          // before block 0: an empty prefix
+                    if (j >= 0) {
+                        do { sw = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((sw >> 62) == 0ull);
+                    }
+                    const unsigned long long pfx = ballot64((sw >> 62) == SCAN_PREFIX);
+                    const int stop = pfx ? __builtin_ctzll(pfx) : 64;              // lanes 0 .. stop take part (stop = 64: all)
+                    unsigned long long h = ((int)lane <= stop) ? ((sw >> 31) & 0x7FFFFFFFull) : 0ull;
+                    unsigned long long k = ((int)lane <= stop) ? (sw & SCAN_KIDS_MAX) : 0ull;
+                    for (int off = 32; off > 0; off >>= 1) { h += __shfl_down(h, off); k += __shfl_down(k, off); }
+                    ph += __shfl(h, 0); pk += __shfl(k, 0);
+                    if (pfx) break;
+                    top -= 64;
+                }
+                if (lane == 0) __hip_atomic_store(&state[bid], scan_pack(SCAN_PREFIX, (uint32_t)(ph + total.x), pk + total.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) { s_prefix[0] = ph; s_prefix[1] = pk; }
+        }
+        __syncthreads();
+        const unsigned long long bh = s_prefix[0], bk = s_prefix[1];
+        const uint32_t kbase = (uint32_t)(bk > SCAN_KIDS_MAX ? SCAN_KIDS_MAX : bk);
+#pragma unroll
+        for (int q = 0; q < SCAN_ITEMS; q++) {
+            if ((uint32_t)q < items) {
+                const uint32_t k = threadIdx.x * items + q;
+                if (k < ng) P.child_base[first + k] = kbase + ex.y + ek[q];
+                hb[k] = (uint32_t)bh + ex.x + eh[q];   // (every thread rewrites only its own slots: the counts it read from them are in registers)
+            }
+        }
+        __syncthreads();
+        // compacted hit list of the block's groups: a wave per group, one thread per ray, coalesced
+        for (uint32_t k = threadIdx.x; k < ng * 64u; k += SCAN_BLOCK) {
+            const uint32_t gl = k >> 6, bit = k & 63u;
+            const unsigned long long m = hm[gl];
             if ((m >> bit) & 1ull)
-                P.hitlist[hb[gl] + (uint32_t)__popcll(m & ((1ull << bit) - 1ull))] = ((b * SCAN_BLOCK + gl) << 6) + bit;
+                P.hitlist[hb[gl] + (uint32_t)__popcll(m & ((1ull << bit) - 1ull))] = ((first + gl) << 6) + bit;
         }
-        __syncthreads();
+        if (bid == nblocks - 1 && threadIdx.x == 0) {
+            const unsigned long long kids = bk + total.y;
+            C->hit_count[g] = (uint32_t)bh + total.x;
+            C->gen_count[g + 1] = (uint32_t)(kids > SCAN_KIDS_MAX ? SCAN_KIDS_MAX : kids);
+            C->gbase[g + 1] = gbase + ngroups;
+            if ((unsigned long long)start + C->gen_count[g] + kids > (unsigned long long)P.capacity) C->overflow = 1;
+        }
+        __syncthreads();                           // hb / hm / s_bid are rewritten by the next round
     }
 }
 
@@ -1111,7 +1193,10 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, ui
 
 // ---------------------------------------------------------------- shadow (any hit)
 // The shadow query of getColor (src/raytrace.cpp:523-539) for every
-// (hit, light) pair of the generation: one work item per pair.
+// (hit, light) pair of the generation: one work item per pair, hit-major (item = hit * lights + light).
+// (Light-major numbering -- a wave holding neighbouring hit points and ONE light -- was measured: the 11 M
+// primitive scene's shadow launches took 61 ms instead of 51; the three rays of a hit share the nodes
+// around their common origin.)
 template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPool P, DCounters* C, int g) {
     __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
@@ -1442,6 +1527,7 @@ static inline int grid_for(uint64_t items, int max_blocks) {
 void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations) {
     hipMemsetAsync(P.wq, 0, (size_t)2 * generations * RT_WQ_LAUNCH * sizeof(uint32_t), st);
     hipMemsetAsync(P.wstats, 0, (size_t)2 * RT_MAX_WAVES * 8 * sizeof(unsigned long long), st);
+    hipMemsetAsync(P.scan_state, 0, P.scan_words * sizeof(unsigned long long) + (RT_MAX_GEN + 1) * sizeof(uint32_t), st);   // state words + tickets (one allocation)
     hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(128), 0, st, C, nsamples);
 }
 // Traversal launches are persistent grids sized to what is RESIDENT at once: with
@@ -1478,11 +1564,9 @@ void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
 }
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {
     uint64_t groups = (bound + 63) / 64;
-    int blocks = (int)std::min<uint64_t>((groups + SCAN_BLOCK - 1) / SCAN_BLOCK, (uint64_t)max_blocks);
+    int blocks = (int)std::min<uint64_t>((groups + SCAN_BLOCK - 1) / SCAN_BLOCK, (uint64_t)std::min<int>(max_blocks, (int)SCAN_TILES_WANTED));
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_scan1, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g);
-    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(SCAN_BLOCK), 0, st, P, C, g);
-    hipLaunchKernelGGL(k_scan3, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g);
+    hipLaunchKernelGGL(k_scan, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g);
 }
 template <bool COUNT>
 static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,

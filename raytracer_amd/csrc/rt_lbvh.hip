@@ -384,9 +384,19 @@ static int ploc_build(hipStream_t st, const Box* boxes, const uint32_t* sorted, 
 // A per-lane walk is a chain of dependent fetches; folding every second level of the binary
 // tree into its parent halves the chain.  Inner nodes at even depth survive; each takes the
 // children of its (odd-depth) inner children, or the child itself where that is a leaf: up
-// to four entries.  Node = 8 float4: 4 boxes as (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z), then the
-// 4 references (>= 0 wide node, < 0 leaf ~slot, RT_REF_NONE empty slot with an inverted box).
-// Ids are the binary ids compacted (prefix sum), so the layout keeps its locality.
+// to four entries.  Ids are the binary ids compacted (prefix sum), so the layout keeps its locality.
+//
+// A wide node is ONE 64-byte record (4 float4): the four child boxes are stored as 8-bit offsets on a
+// grid laid over the node's own box -- origin = the low corner of the union of the children, one
+// power-of-two step per axis -- so a step of the walk moves 64 bytes instead of 128 (the walks of scenes
+// far larger than the caches are bound by exactly those bytes):
+//   q0 = (origin.x, origin.y, origin.z, bits: biased exponent of the x | y << 8 | z << 16 step)
+//   q1 = bits (lo.x of the 4 children, one byte each) (lo.y) (lo.z) (hi.x)
+//   q2 = bits (hi.y) (hi.z), ref0, ref1          q3 = ref2, ref3, -, -
+// ref >= 0 wide node, < 0 leaf ~slot, RT_REF_NONE empty slot (its box is inverted: lo 255, hi 0).
+// Quantisation only ever GROWS a box: lo is rounded down and moved one more step down, hi up and one more
+// up (clamped to the grid, whose ends are the union's own faces or beyond), which also covers the
+// rounding of the walk's decode; the exact primitive tests decide every hit, so the image cannot change.
 #define RT_REF_NONE ((int)0x80000000)
 
 __global__ void k_w4_parent(const float4* nodes, int m, int* parent) {
@@ -408,7 +418,10 @@ __device__ inline void w4_entry(float* dst, int* refs, int k, const float* box, 
     for (int t = 0; t < 6; t++) dst[6 * k + t] = box[t];
     refs[k] = ref;
 }
-__global__ void k_w4_collapse(const float4* nodes, int m, const uint32_t* flag, const uint32_t* idx, float4* out) {
+// The plain form of a wide node, for trees that fit the caches (there a step of the walk is bound by latency
+// and the arithmetic of decoding bytes only lengthens it): 8 float4 = the 4 boxes as (lo.x, hi.x, lo.y, hi.y,
+// lo.z, hi.z), then the 4 references.
+__global__ void k_w4_collapse_exact(const float4* nodes, int m, const uint32_t* flag, const uint32_t* idx, float4* out) {
     int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= m || !flag[v]) return;
     const float* src = (const float*)(nodes + 4 * (size_t)v);
@@ -431,8 +444,65 @@ __global__ void k_w4_collapse(const float4* nodes, int m, const uint32_t* flag, 
     dst[7] = make_float4(0, 0, 0, 0);
 }
 
-// nodes: binary tree of m inner nodes, root 0.  -> *out (8 float4 per wide node, root 0), or nullptr on failure.
-static void collapse4(hipStream_t st, const float4* nodes, int m, float4** out) {
+__global__ void k_w4_collapse(const float4* nodes, int m, const uint32_t* flag, const uint32_t* idx, float4* out) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m || !flag[v]) return;
+    const float* src = (const float*)(nodes + 4 * (size_t)v);
+    float box[24]; int refs[4];       // per child (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
+    int k = 0;
+    for (int s = 0; s < 2; s++) {
+        int c = __float_as_int(src[12 + s]);
+        if (c < 0) { w4_entry(box, refs, k++, src + 6 * s, c); continue; }
+        const float* cs = (const float*)(nodes + 4 * (size_t)c);
+        for (int t = 0; t < 2; t++) {
+            int g = __float_as_int(cs[12 + t]);
+            w4_entry(box, refs, k++, cs + 6 * t, g < 0 ? g : (int)idx[g]);
+        }
+    }
+    const int nvalid = k;
+    for (; k < 4; k++) refs[k] = RT_REF_NONE;
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, ebits = 0;
+    float origin[3];
+    for (int a = 0; a < 3; a++) {
+        float lo = box[2 * a], hi = box[2 * a + 1];
+        for (int c = 1; c < nvalid; c++) { lo = fminf(lo, box[6 * c + 2 * a]); hi = fmaxf(hi, box[6 * c + 2 * a + 1]); }
+        // step = the smallest power of two with 253 steps >= the extent (two steps of the 255 are the margin), but
+        // never below 2^-20 of the coordinates' magnitude: a flat box keeps a margin well above float rounding
+        int ex = 0;
+        const float mant = frexpf((hi - lo) / 253.0f, &ex);            // extent / 253 = mant * 2^ex, mant in [0.5, 1)
+        (void)mant;
+        int em = 0;
+        (void)frexpf(fmaxf(fabsf(lo), fabsf(hi)), &em);
+        if (hi - lo == 0.0f) ex = -100;                                  // (frexp of zero reports exponent 0)
+        ex = max(ex, em - 20);
+        ex = max(-100, min(100, ex));
+        if (!(hi - lo >= 0.0f) || !(fabsf(lo) < __builtin_inff()) || !(fabsf(hi) < __builtin_inff())) ex = 100;   // NaN / infinite boxes: everything maps to the grid's ends
+        const float step = ldexpf(1.0f, ex);
+        origin[a] = lo;
+        ebits |= (uint32_t)(ex + 127) << (8 * a);
+        for (int c = 0; c < 4; c++) {
+            uint32_t l = 255u, h = 0u;                                   // empty slot: inverted
+            if (c < nvalid) {
+                const float fl = floorf((box[6 * c + 2 * a] - lo) / step) - 1.0f;
+                const float fh = ceilf((box[6 * c + 2 * a + 1] - lo) / step) + 1.0f;
+                l = (uint32_t)fminf(fmaxf(fl, 0.0f), 255.0f);
+                h = (uint32_t)fminf(fmaxf(fh, 0.0f), 255.0f);
+                if (!(fl == fl)) l = 0u;                                 // NaN coordinates: the whole grid
+                if (!(fh == fh)) h = 255u;
+            }
+            qlo[a] |= l << (8 * c);
+            qhi[a] |= h << (8 * c);
+        }
+    }
+    float4* dst = out + 4 * (size_t)idx[v];
+    dst[0] = make_float4(origin[0], origin[1], origin[2], __uint_as_float(ebits));
+    dst[1] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qlo[1]), __uint_as_float(qlo[2]), __uint_as_float(qhi[0]));
+    dst[2] = make_float4(__uint_as_float(qhi[1]), __uint_as_float(qhi[2]), __int_as_float(refs[0]), __int_as_float(refs[1]));
+    dst[3] = make_float4(__int_as_float(refs[2]), __int_as_float(refs[3]), 0.0f, 0.0f);
+}
+
+// nodes: binary tree of m inner nodes, root 0.  -> *out (root 0; 4 float4 per wide node when quantised, else 8), or nullptr on failure.
+static void collapse4(hipStream_t st, const float4* nodes, int m, bool quantised, float4** out) {
     *out = nullptr;
     int* parent = nullptr; uint32_t *flag = nullptr, *idx = nullptr; void* tmp = nullptr; float4* wide = nullptr;
     auto cleanup = [&]() { (void)hipFree(parent); (void)hipFree(flag); (void)hipFree(idx); (void)hipFree(tmp); };
@@ -451,8 +521,9 @@ static void collapse4(hipStream_t st, const float4* nodes, int m, float4** out) 
         hipMemcpyAsync(&last[1], idx + (m - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) return fail();
     const size_t m4 = (size_t)last[0] + last[1];
-    if (m4 < 1 || hipMalloc(&wide, m4 * 8 * sizeof(float4)) != hipSuccess) return fail();
-    hipLaunchKernelGGL(k_w4_collapse, grid, block, 0, st, nodes, m, flag, idx, wide);
+    if (m4 < 1 || hipMalloc(&wide, m4 * (quantised ? 4 : 8) * sizeof(float4)) != hipSuccess) return fail();
+    if (quantised) hipLaunchKernelGGL(k_w4_collapse, grid, block, 0, st, nodes, m, flag, idx, wide);
+    else hipLaunchKernelGGL(k_w4_collapse_exact, grid, block, 0, st, nodes, m, flag, idx, wide);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail();
     cleanup();
     *out = wide;
@@ -467,7 +538,7 @@ static void collapse4(hipStream_t st, const float4* nodes, int m, float4** out) 
 // by the caller.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
               int** prim_idx_out, float4** leaf_out, int* depth, int ploc_radius, float4** ploc_out,
-              int* ploc_depth, float4** wide_out, float4** ploc_wide_out) {
+              int* ploc_depth, float4** wide_out, float4** ploc_wide_out, int wide_quantised) {
     int n = ns + nt;
     *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *ploc_out = nullptr; *ploc_depth = 0;
     *wide_out = nullptr; *ploc_wide_out = nullptr;
@@ -514,14 +585,14 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
         if (hipMalloc(&pn, (size_t)(n - 1) * 4 * sizeof(float4)) == hipSuccess &&
             ploc_build(st, boxes, vals2, n, ploc_radius, pn, &r, &d) == (int)hipSuccess && d <= 64) {
             *ploc_out = pn; *ploc_depth = d;
-            collapse4(st, pn, n - 1, ploc_wide_out);
+            collapse4(st, pn, n - 1, wide_quantised != 0, ploc_wide_out);
         } else {
             (void)hipFree(pn);
             (void)hipGetLastError();
         }
     }
     // 4-wide versions for the per-lane walks (their stacks hold up to 3 entries per wide level: depth <= 64)
-    if (*depth <= 64) collapse4(st, nodes, n - 1, wide_out);
+    if (*depth <= 64) collapse4(st, nodes, n - 1, wide_quantised != 0, wide_out);
     L_TRY(hipGetLastError());
     L_TRY(hipStreamSynchronize(st));
     cleanup();

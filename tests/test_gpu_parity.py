@@ -199,6 +199,38 @@ def test_lbvh_equals_brute_force_on_random_rays(tracer, name):
         assert np.array_equal(ab >= 0, al >= 0)
 
 
+@pytest.mark.parametrize("name", ["dragon", "plant_h", "spheres2"])
+def test_quantised_wide_nodes_equal_brute_force(monkeypatch, name):
+    """Trees beyond the caches store their 4-wide nodes with 8-bit child boxes (conservatively rounded outward);
+    forced here on scenes that would get float boxes: the per-lane wide walk of both hierarchies must still find
+    the brute-force hit for every ray, closest-hit and any-hit, and render the same image."""
+    scene = load_scene(name).copy(width=160, height=120, spp=2)
+    rng = np.random.default_rng(17)
+    o, d = _random_rays(scene, 100_000, rng)
+    monkeypatch.setenv("RT_WIDE_QUANT", "1")
+    monkeypatch.setenv("RT_PACKET_GENS", "0")
+    monkeypatch.setenv("RT_PACKET_SHADOW_GENS", "0")
+    monkeypatch.setenv("RT_LANE_WIDE", "1")
+    with ra.Tracer(accel=ra.RT_ACCEL_LBVH) as t:
+        t.load_scene(scene)
+        pb, db = t.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
+        dmax = np.where(rng.random(len(o)) < 0.5, db * rng.uniform(0.5, 1.5, len(o)).astype(np.float32), np.float32(np.inf)).astype(np.float32)
+        dmax[~np.isfinite(dmax)] = np.inf
+        ab, _ = t.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_BRUTE)
+        for accel in (ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE):
+            pl, dl = t.query_rays(o, d, accel=accel)
+            assert np.array_equal(pb, pl), f"accel {accel}: {(pb != pl).sum()} closest hits differ"
+            assert np.array_equal(bits(db), bits(dl))
+            al, _ = t.query_rays(o, d, dmax=dmax, any_hit=True, accel=accel)
+            assert np.array_equal(ab >= 0, al >= 0)
+        rgb_q, f_q, st_q = t.render(want_float=True)
+    monkeypatch.setenv("RT_WIDE_QUANT", "0")
+    with ra.Tracer(accel=ra.RT_ACCEL_LBVH) as t:
+        t.load_scene(scene)
+        rgb_f, f_f, st_f = t.render(want_float=True)
+    assert np.array_equal(rgb_q, rgb_f) and np.array_equal(bits(f_q), bits(f_f)) and st_q.rays == st_f.rays
+
+
 def test_query_matches_oracle_on_random_rays(oracle, tracer):
     scene = load_scene("complex_test")
     tracer.load_scene(scene)
