@@ -4,7 +4,7 @@
 // is incomplete (it drops large triangles) and is not reproduced.  Built fresh:
 //   1. per-primitive padded AABB + scene bounds (block reduce + float atomics)
 //   2. 63-bit Morton code of the box centre (21 bits per axis)
-//   3. radix sort of (code, primitive id) pairs            [rocPRIM device sort]
+//   3. radix sort of (code, primitive id) pairs            [rt_sort.h: eight 8-bit passes, wave64 ballots]
 //   4. Karras 2012: one thread per inner node finds its key range and split
 //   5. bottom-up refit: the second thread to arrive at a node merges the boxes
 // The tree only has to be CONSERVATIVE: traversal re-runs the reference's exact
@@ -16,7 +16,9 @@
 #include "rt_kernels.h"
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
+#include <utility>
+
+#include "rt_sort.h"
 
 struct Box { float lo[3], hi[3]; };
 
@@ -339,9 +341,7 @@ static int ploc_build(hipStream_t st, const Box* boxes, const uint32_t* sorted, 
     P_TRY(hipMalloc(&parent, (size_t)n * sizeof(int))); P_TRY(hipMalloc(&inner, (size_t)n * sizeof(int)));
     P_TRY(hipMalloc(&pos, (size_t)n * sizeof(int)));
     P_TRY(hipMalloc(&flags, (size_t)n * 8)); P_TRY(hipMalloc(&pref, (size_t)n * 8));
-    size_t tmp_bytes = 0;
-    P_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pref, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
-    P_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+    P_TRY(hipMalloc(&tmp, rts_scan_temp_bytes<unsigned long long>((size_t)n)));
     hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, st, boxes, sorted, n, lo[0], hi[0]);
     int count = n, node_base = 0, cur = 0, rounds = 0;
     while (count > 1) {
@@ -349,7 +349,7 @@ static int ploc_build(hipStream_t st, const Box* boxes, const uint32_t* sorted, 
         dim3 grid((count + 255) / 256), block(256);
         hipLaunchKernelGGL(k_ploc_nn, grid, block, 0, st, lo[cur], hi[cur], count, radius, nn);
         hipLaunchKernelGGL(k_ploc_flag, grid, block, 0, st, nn, count, flags);
-        P_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, flags, pref, 0ull, (size_t)count, rocprim::plus<unsigned long long>(), st));
+        P_TRY(rts_exclusive_scan<unsigned long long>(tmp, flags, pref, (size_t)count, st));
         hipLaunchKernelGGL(k_ploc_merge, grid, block, 0, st, lo[cur], hi[cur], nn, flags, pref, count, node_base, nodes,
                            parent, inner, lo[cur ^ 1], hi[cur ^ 1]);
         unsigned long long last[2];
@@ -512,10 +512,8 @@ static void collapse4(hipStream_t st, const float4* nodes, int m, bool quantised
     dim3 grid((m + 255) / 256), block(256);
     hipLaunchKernelGGL(k_w4_parent, grid, block, 0, st, nodes, m, parent);
     hipLaunchKernelGGL(k_w4_flag, grid, block, 0, st, parent, m, 0, flag);
-    size_t tmp_bytes = 0;
-    if (rocprim::exclusive_scan(nullptr, tmp_bytes, flag, idx, 0u, (size_t)m, rocprim::plus<uint32_t>(), st) != hipSuccess) return fail();
-    if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) return fail();
-    if (rocprim::exclusive_scan(tmp, tmp_bytes, flag, idx, 0u, (size_t)m, rocprim::plus<uint32_t>(), st) != hipSuccess) return fail();
+    if (hipMalloc(&tmp, rts_scan_temp_bytes<uint32_t>((size_t)m)) != hipSuccess) return fail();
+    if (rts_exclusive_scan<uint32_t>(tmp, flag, idx, (size_t)m, st) != hipSuccess) return fail();
     uint32_t last[2] = {0, 0};
     if (hipMemcpyAsync(&last[0], flag + (m - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(&last[1], idx + (m - 1), 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -567,10 +565,21 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     int blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, sph, ns, tri, n, boxes, scene);
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, st, boxes, n, scene, keys, vals);
-    size_t tmp_bytes = 0;
-    L_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, st));
-    L_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
-    L_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0, 63, st));
+    L_TRY(hipMalloc(&tmp, rts_sort_temp_bytes((size_t)n)));
+    {
+        bool in_alt = false;
+        L_TRY(rts_sort_pairs(tmp, keys, keys2, vals, vals2, (size_t)n, 63, st, &in_alt));
+        if (!in_alt) { std::swap(keys, keys2); std::swap(vals, vals2); }      // keys2 / vals2 = the sorted pairs from here on
+        // A hierarchy over keys that are not sorted can contain cycles, and a walk through a cycle never ends:
+        // check the order and that the values are still the ids 0 .. n-1 before anything is built on them.
+        unsigned long long* chk = (unsigned long long*)tmp;
+        L_TRY(hipMemsetAsync(chk, 0, 16, st));
+        hipLaunchKernelGGL(k_rts_check_sorted, dim3(blocks), dim3(256), 0, st, keys2, vals2, (size_t)n, chk);
+        unsigned long long got[2] = {1, 0};
+        L_TRY(hipMemcpyAsync(got, chk, 16, hipMemcpyDeviceToHost, st));
+        L_TRY(hipStreamSynchronize(st));
+        if (got[0] != 0 || got[1] != (unsigned long long)n * (unsigned long long)(n - 1) / 2) L_TRY(hipErrorUnknown);
+    }
     hipLaunchKernelGGL(k_leaves, dim3(blocks), dim3(256), 0, st, sph, ns, tri, vals2, n, leaf);
     hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, st, keys2, n, child, pin, plf);
     hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, boxes, vals2, n, child, pin, plf, flags, nodes);
