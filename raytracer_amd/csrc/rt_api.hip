@@ -159,7 +159,7 @@ static void free_pool(rt_ctx* c) {
     hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.hd); hipFree(c->P.loc);
     hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.link); hipFree(c->P.wstats); hipFree(c->P.occl); hipFree(c->P.scol);
     hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr);
-    hipFree(c->P.child_base); hipFree(c->P.scan_state); hipFree(c->P.hitlist); hipFree(c->P.wq);
+    hipFree(c->P.child_base); hipFree(c->P.scan_state); hipFree(c->P.hitlist);   // (scan_ticket and wq lie in scan_state's allocation)
     hipFree(c->hp2); hipFree(c->hn2); hipFree(c->hd2); hipFree(c->hitlist2);
     c->hp2 = c->hn2 = c->hd2 = nullptr; c->hitlist2 = nullptr; c->alt_capacity = 0;
     c->P = DPool{};
@@ -476,13 +476,18 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.mask_refl, groups * 8));
     HIP_TRY(hipMalloc(&c->P.mask_refr, groups * 8));
     HIP_TRY(hipMalloc(&c->P.child_base, groups * 4));
-    c->P.scan_words = sblocks + RT_MAX_GEN + 8;       // generation g starts at word (groups before it >> 8) + g
-    HIP_TRY(hipMalloc(&c->P.scan_state, c->P.scan_words * sizeof(unsigned long long) + (RT_MAX_GEN + 1) * sizeof(uint32_t)));
+    // everything a batch needs zeroed lies in ONE allocation, cleared by one fill per batch: the scan's state words
+    // (generation g starts at word (groups before it >> 8) + g), its tickets, then the work-queue counters of
+    // the traversal launches (two launches per generation; only the generations in use are cleared)
+    c->P.scan_words = sblocks + RT_MAX_GEN + 8;
+    const size_t ticket_bytes = ((RT_MAX_GEN + 1) * sizeof(uint32_t) + 127) / 128 * 128;
+    HIP_TRY(hipMalloc(&c->P.scan_state, c->P.scan_words * sizeof(unsigned long long) + ticket_bytes +
+                                            (size_t)2 * (RT_MAX_GEN + 1) * RT_WQ_LAUNCH * sizeof(uint32_t)));
     c->P.scan_ticket = (uint32_t*)(c->P.scan_state + c->P.scan_words);
+    c->P.wq = (uint32_t*)((char*)c->P.scan_ticket + ticket_bytes);
     HIP_TRY(hipMalloc(&c->P.hitlist, capacity * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->P.occl, occl));
     HIP_TRY(hipMalloc(&c->P.scol, samples * sizeof(float4)));
-    HIP_TRY(hipMalloc(&c->P.wq, (size_t)2 * (RT_MAX_GEN + 1) * RT_WQ_LAUNCH * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->P.link, capacity * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->P.wstats, (size_t)2 * RT_MAX_WAVES * 8 * sizeof(unsigned long long)));
     c->P.capacity = (uint32_t)capacity;
@@ -593,7 +598,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     const uint64_t cap = c->P.capacity;
     const auto host_t0 = std::chrono::steady_clock::now();
     tm.mark(3);
-    rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1);
+    rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1, c->count_work || S.profile);
     tm.mark(3);
     if (S.max_depth < 0) rtk_fill_background(st, S, c->P, nsamples, c->max_blocks);   // nothing is traced at all
     LAUNCH_CHECK("init", -1);
@@ -780,29 +785,38 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                     for (int g = 0; g < G; g++) te[t][mode][g] = tsh[t][mode][g] = 1e30f;
                     continue;
                 }
-                hipStream_t st = c->stream;
-                rtk_init_counters(st, c->d_counters, nsamples, c->P, G);
-                uint64_t bound = nsamples;
-                for (int g = 0; g < G; g++) {
-                    hipEventRecord(ev[4 * g + 0], st);
-                    rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false, c->launch_cache);
-                    hipEventRecord(ev[4 * g + 1], st);
-                    rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
-                    hipEventRecord(ev[4 * g + 2], st);
-                    rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false, c->launch_cache);
-                    hipEventRecord(ev[4 * g + 3], st);
-                    rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
-                    CAL_TRY(hipGetLastError());        // a rejected launch of this generation, named by the expression
-                    bound = std::min<uint64_t>(bound * 2, c->P.capacity);
-                }
-                DCounters hc;
-                if (hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess) { ok = false; n = 0; break; }
-                if (hc.overflow) { ok = false; break; }      // sample does not fit the pool: halve it
-                for (int g = 0; g < G; g++) {
-                    sample_rays[g] = hc.gen_count[g];
-                    hipEventElapsedTime(&te[t][mode][g], ev[4 * g + 0], ev[4 * g + 1]);
-                    hipEventElapsedTime(&tsh[t][mode][g], ev[4 * g + 2], ev[4 * g + 3]);
+                // (timing small samples three times and keeping the fastest was tried: the choice still flips between runs
+                // on the thinnest frames -- the two walks are within a few per cent there -- and the first frame trebles)
+                const int reps = 1;
+                for (int g = 0; g < G; g++) te[t][mode][g] = tsh[t][mode][g] = 1e30f;
+                for (int rep = 0; rep < reps && ok; rep++) {
+                    hipStream_t st = c->stream;
+                    rtk_init_counters(st, c->d_counters, nsamples, c->P, G, false);
+                    uint64_t bound = nsamples;
+                    for (int g = 0; g < G; g++) {
+                        hipEventRecord(ev[4 * g + 0], st);
+                        rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false, c->launch_cache);
+                        hipEventRecord(ev[4 * g + 1], st);
+                        rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
+                        hipEventRecord(ev[4 * g + 2], st);
+                        rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false, c->launch_cache);
+                        hipEventRecord(ev[4 * g + 3], st);
+                        rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
+                        CAL_TRY(hipGetLastError());        // a rejected launch of this generation, named by the expression
+                        bound = std::min<uint64_t>(bound * 2, c->P.capacity);
+                    }
+                    DCounters hc;
+                    if (hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess) { ok = false; n = 0; break; }
+                    if (hc.overflow) { ok = false; break; }      // sample does not fit the pool: halve it
+                    for (int g = 0; g < G; g++) {
+                        float a = 1e30f, b = 1e30f;
+                        sample_rays[g] = hc.gen_count[g];
+                        hipEventElapsedTime(&a, ev[4 * g + 0], ev[4 * g + 1]);
+                        hipEventElapsedTime(&b, ev[4 * g + 2], ev[4 * g + 3]);
+                        te[t][mode][g] = std::min(te[t][mode][g], a);
+                        tsh[t][mode][g] = std::min(tsh[t][mode][g], b);
+                    }
                 }
             }
         }

@@ -131,7 +131,8 @@ struct DPool {
     // ... and their prefix sums, for the current generation only (index = group)
     uint32_t* child_base;  // next-generation rays before the group
     // single-pass scan: one state word per 256 groups of every generation of the batch (zeroed per batch), and
-    // a block ticket per generation; scan_ticket lies right behind the scan_words state words (one allocation)
+    // a block ticket per generation; scan_ticket lies right behind the scan_words state words and wq behind it
+    // (one allocation, cleared by one fill per batch)
     unsigned long long* scan_state;
     uint32_t* scan_ticket;
     uint64_t scan_words;

@@ -12,7 +12,7 @@ struct RtkLaunchCache {
     int shadow[2][5] = {{0}};
 };
 
-void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations);
+void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations, bool count_work);
 // generation 0 is generated on the fly from (cam, tiles, tile0); deeper generations read the pool
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
                 const uint32_t* tiles, uint32_t tile0, int g, uint64_t bound, int max_blocks, bool count,

@@ -1524,10 +1524,11 @@ static inline int grid_for(uint64_t items, int max_blocks) {
     return (int)b;
 }
 
-void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations) {
-    hipMemsetAsync(P.wq, 0, (size_t)2 * generations * RT_WQ_LAUNCH * sizeof(uint32_t), st);
-    hipMemsetAsync(P.wstats, 0, (size_t)2 * RT_MAX_WAVES * 8 * sizeof(unsigned long long), st);
-    hipMemsetAsync(P.scan_state, 0, P.scan_words * sizeof(unsigned long long) + (RT_MAX_GEN + 1) * sizeof(uint32_t), st);   // state words + tickets (one allocation)
+void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations, bool count_work) {
+    // scan state words, scan tickets and the work-queue counters of the generations in use: one contiguous run
+    const size_t zero_bytes = (size_t)((char*)(P.wq + (size_t)2 * (generations > 0 ? generations : 1) * RT_WQ_LAUNCH) - (char*)P.scan_state);
+    hipMemsetAsync(P.scan_state, 0, zero_bytes, st);
+    if (count_work) hipMemsetAsync(P.wstats, 0, (size_t)2 * RT_MAX_WAVES * 8 * sizeof(unsigned long long), st);
     hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(128), 0, st, C, nsamples);
 }
 // Traversal launches are persistent grids sized to what is RESIDENT at once: with
