@@ -30,8 +30,11 @@
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES)))
 #else
 // the per-lane walks hide memory latency with waves: 5 per SIMD at the price of a few spilled dwords;
-// the packet walks fit 6 without spilling
-#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : (ACCEL == 3 ? RT_PACKET_WAVES : 1), 8)))
+// the packet walks fit 6 without spilling -- and MUST NOT spill: their traversal stack lives in the lanes of
+// a vector register written with v_writelane, and a spill of it under a partial EXEC mask would lose entries.
+// Their counting variants carry more live values, so they settle for 5 waves (measurement only); the build
+// fails if any packet kernel uses scratch memory (tools/isa_stats.py --check).
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : (ACCEL == 3 ? (COUNT ? RT_PACKET_WAVES - 1 : RT_PACKET_WAVES) : 1), 8)))
 #endif
 #ifndef RT_LANE_WAVES
 #define RT_LANE_WAVES 5
