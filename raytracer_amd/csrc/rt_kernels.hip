@@ -302,9 +302,41 @@ __device__ __forceinline__ void order2(float& ka, int& ra, float& kb, int& rb) {
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
-template <bool WIDE>
-__device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const SlabRay& R, float tmax, int* stack,
-                                               int& sp, TraceStats& ts) {
+// Traversal stack of one lane, two ways.  PrivateStack: an array in the lane's private (scratch) memory, as deep
+// as any tree can need.  LdsStack: entry k of the block's thread t at lds[k * RT_BLOCK + t] (a wave reads one row:
+// no bank conflicts beyond the two halves of the wave), LANE_LDS_STACK deep; a walk that would go deeper sets
+// `over` and its caller redoes that one ray with a PrivateStack.  On a scene far larger than the caches the pushes
+// of the private stacks are HBM traffic -- the stacks of all resident waves together (130 MB) are many times the
+// L2, measured 5.8 GB written per 10 M-ray shadow launch of the 11 M-primitive scene -- which LDS takes away.
+#ifndef LANE_LDS_STACK
+#define LANE_LDS_STACK 24
+#endif
+struct PrivateStack {      // (the array itself is a local of the caller: a struct that held it would drag sp into memory with it)
+    int* e;                // [LBVH_STACK]
+    int sp;
+    __device__ __forceinline__ void reset() { sp = 0; }
+    __device__ __forceinline__ void push(int v) { if (sp < LBVH_STACK) e[sp++] = v; }
+    __device__ __forceinline__ bool empty() const { return sp <= 0; }
+    __device__ __forceinline__ int pop() { return e[--sp]; }
+};
+struct LdsStack {
+    int* col;          // this lane's column of the block's LDS area
+    int sp;
+    bool over;
+    __device__ __forceinline__ void init(int* block_lds) { col = block_lds + threadIdx.x; sp = 0; over = false; }
+    __device__ __forceinline__ void reset() { sp = 0; over = false; }
+    __device__ __forceinline__ void push(int v) {
+        if (sp < LANE_LDS_STACK) col[sp * RT_BLOCK] = v;
+        else over = true;
+        sp++;
+    }
+    __device__ __forceinline__ bool empty() const { return sp <= 0; }
+    __device__ __forceinline__ int pop() { --sp; return col[(sp < LANE_LDS_STACK ? sp : LANE_LDS_STACK - 1) * RT_BLOCK]; }
+};
+#define LANE_STACK_F4 (LANE_LDS_STACK * RT_BLOCK / 4)        // float4 slots of LDS a block of walkers with LdsStacks needs
+
+template <bool WIDE, class STK>
+__device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const SlabRay& R, float tmax, STK& stk, TraceStats& ts) {
     // counted in 64-byte records fetched and box pairs tested: a wide node is two pairs, and one record when its
     // boxes are quantised, two when they are floats
     ts.nodes += (WIDE && !S.wide_quant) ? 2 : 1; ts.lane_nodes += WIDE ? 2 : 1;
@@ -317,12 +349,12 @@ __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const S
         const int c0 = (int)fbits(q3.x), c1 = (int)fbits(q3.y);
         if (h0 && h1) {
             const bool swap = tn1 < tn0;
-            if (sp < LBVH_STACK) stack[sp++] = swap ? c0 : c1;
+            stk.push(swap ? c0 : c1);
             return swap ? c1 : c0;
         }
         if (h0) return c0;
         if (h1) return c1;
-        return sp > 0 ? stack[--sp] : LANE_DONE;
+        return stk.empty() ? LANE_DONE : stk.pop();
     } else {
         float k0, k1, k2, k3;
         bool h0, h1, h2, h3;
@@ -364,11 +396,11 @@ __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const S
         order2(k0, r0, k1, r1); order2(k2, r2, k3, r3);      // sorting network for four
         order2(k0, r0, k2, r2); order2(k1, r1, k3, r3);
         order2(k1, r1, k2, r2);
-        if (k3 < inf && sp < LBVH_STACK) stack[sp++] = r3;   // farthest first: the nearer ones come off first
-        if (k2 < inf && sp < LBVH_STACK) stack[sp++] = r2;
-        if (k1 < inf && sp < LBVH_STACK) stack[sp++] = r1;
+        if (k3 < inf) stk.push(r3);   // farthest first: the nearer ones come off first
+        if (k2 < inf) stk.push(r2);
+        if (k1 < inf) stk.push(r1);
         if (k0 < inf) return r0;
-        return sp > 0 ? stack[--sp] : LANE_DONE;
+        return stk.empty() ? LANE_DONE : stk.pop();
     }
 }
 
@@ -382,12 +414,12 @@ __device__ __forceinline__ void lbvh_trace(const DScene& S, bool active, F3 o, F
     double dd = (double)dot3(d, d);
     const SlabRay R = slab_ray(o, d);
     float tmax = slab_tmax(R, dmax);
-    int stack[LBVH_STACK];
-    int sp = 0;
+    int stack_mem[LBVH_STACK];
+    PrivateStack stk{stack_mem, 0};
     int cur = 0;                                   // both trees keep their root at node 0
     while (cur != LANE_DONE) {
         if (cur >= 0) {
-            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stack, sp, ts);
+            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stk, ts);
         } else {
             const float4* lf = S.leaf + 3 * (size_t)(~cur);
             float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
@@ -405,7 +437,7 @@ __device__ __forceinline__ void lbvh_trace(const DScene& S, bool active, F3 o, F
                     tmax = slab_tmax(R, d2);
                 }
             }
-            cur = sp > 0 ? stack[--sp] : LANE_DONE;
+            cur = stk.empty() ? LANE_DONE : stk.pop();
         }
     }
 }
@@ -825,7 +857,7 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
 // together at the end from one flag byte per ray kept in LDS (`flags`, this wave's own).
 template <bool WIDE>
 __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
-                                    uint32_t gbase, uint32_t first, uint32_t n, uint8_t* flags, TraceStats& ts) {
+                                    uint32_t gbase, uint32_t first, uint32_t n, uint8_t* flags, int* lds_stack, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     enum { IDLE = 0, WALK = 1, FIN = 2 };
@@ -837,9 +869,10 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
     float tmax = 0, best_d2 = 0;
     double dd = 1;
     SlabRay R = slab_ray(o, d);
-    int cur = LANE_DONE, sp = 0, best = -1;
+    int cur = LANE_DONE, best = -1;
     HitUV uv; uv.a = 0; uv.b = 0;
-    int stack[LBVH_STACK];
+    LdsStack stk;
+    stk.init(lds_stack);
     auto begin = [&](uint32_t rel) {
         RayRec rr = load_ray(P, G, g, first + rel, start + first + rel);
         o = rr.o; d = rr.d; parent = rr.parent; slot = rr.slot; valid = rr.valid;
@@ -847,7 +880,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
         dd = (double)dot3(d, d);
         R = slab_ray(o, d);
         tmax = __builtin_inff();
-        cur = 0; sp = 0;                            // both trees keep their root at node 0
+        cur = 0; stk.reset();                       // both trees keep their root at node 0
         state = valid ? WALK : FIN;
     };
     if (k < n) begin(k);
@@ -855,7 +888,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
         if (ballot64(state != IDLE) == 0ull) break;
         const bool at_node = state == WALK && cur >= 0;
         if (at_node) {
-            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stack, sp, ts);
+            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stk, ts);
             if (cur == LANE_DONE) state = FIN;
         }
         // lanes at a leaf wait until LEAF_MIN of them are (see shadow_chunk)
@@ -876,9 +909,15 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
                         tmax = slab_tmax(R, d2);
                     }
                 }
-                if (sp > 0) cur = stack[--sp];
+                if (!stk.empty()) cur = stk.pop();
                 else state = FIN;
             }
+        }
+        if (state == WALK && stk.over) {
+            // deeper than the LDS stack holds (rare): this one ray again, on a stack in private memory
+            lbvh_trace<false, WIDE>(S, true, o, d, __builtin_inff(), best, best_d2, uv, ts);
+            stk.reset();
+            state = FIN;
         }
         const unsigned long long fin = ballot64(state == FIN);
         if (__popcll(fin) >= REFILL_MIN || ballot64(state == WALK) == 0ull) {
@@ -927,7 +966,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
 
 template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : 1];
     if (C->overflow) return;   // ray slots past an overflow were never written: the host re-runs the batch
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
@@ -951,7 +990,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
         } else {
             for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + span - 1) / span, [&](uint64_t c) {
                 const uint32_t first = (uint32_t)c * span;
-                extend_chunk<ACCEL == 4>(S, P, G, g, start, gbase, first, min(span, count - first), flags[threadIdx.x >> 6], ts);
+                extend_chunk<ACCEL == 4>(S, P, G, g, start, gbase, first, min(span, count - first), flags[threadIdx.x >> 6], (int*)lds, ts);
             });
         }
     } else {
@@ -1127,7 +1166,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(DPool P, DCounters* C, int 
 // wave stays full until the chunk runs out.  One loop iteration = one node or one leaf per
 // lane, exactly the step of lbvh_trace<true>.
 template <bool WIDE>
-__device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, uint64_t first, uint64_t end, TraceStats& ts) {
+__device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, int* lds_stack, uint64_t first, uint64_t end, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t nl = (uint32_t)S.nl;
@@ -1139,8 +1178,9 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, ui
     float dmax = 0, tmax = 0;
     double dd = 1;
     SlabRay R = slab_ray(o, d);
-    int cur = LANE_DONE, sp = 0;
-    int stack[LBVH_STACK];
+    int cur = LANE_DONE;
+    LdsStack stk;
+    stk.init(lds_stack);
     auto start = [&](uint32_t rel) {
         const uint64_t item = first + rel;
         uint32_t h = (uint32_t)(item / nl);
@@ -1151,14 +1191,14 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, ui
         R = slab_ray(o, d);
         tmax = slab_tmax(R, dmax);
         cur = 0;                                    // both trees keep their root at node 0
-        sp = 0;
+        stk.reset();
     };
     if (alive) start(k);
     while (ballot64(alive) != 0ull) {
         int verdict = -1;                // 0: reaches the light, 1: occluded
         const bool at_node = alive && cur >= 0;
         if (at_node) {
-            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stack, sp, ts);
+            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stk, ts);
             if (cur == LANE_DONE) verdict = 0;
         }
         // The exact primitive test is four times the cost of a node step and only a few lanes
@@ -1175,9 +1215,16 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, ui
                 float d2 = 0;
                 HitUV cand;
                 if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand)) verdict = 1;
-                else if (sp > 0) cur = stack[--sp];
+                else if (!stk.empty()) cur = stk.pop();
                 else verdict = 0;
             }
+        }
+        if (alive && stk.over) {
+            // deeper than the LDS stack holds (rare): this one ray again, on a stack in private memory
+            int b; float bd; HitUV buv;
+            lbvh_trace<true, WIDE>(S, true, o, d, dmax, b, bd, buv, ts);
+            verdict = b >= 0 ? 1 : 0;
+            stk.reset();
         }
         if (verdict >= 0) {
             P.occl[first + k] = (uint8_t)verdict;
@@ -1202,7 +1249,7 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, ui
 // around their common origin.)
 template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPool P, DCounters* C, int g) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : 1];
     if (C->overflow) return;
     const uint32_t nh = C->hit_count[g];
     const uint64_t items = (uint64_t)nh * (uint64_t)S.nl;
@@ -1234,7 +1281,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
         } else {
             for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + span - 1) / span, [&](uint64_t c) {
                 const uint64_t first = c * span;
-                shadow_chunk<ACCEL == 4>(S, P, first, first + span < items ? first + span : items, ts);
+                shadow_chunk<ACCEL == 4>(S, P, (int*)lds, first, first + span < items ? first + span : items, ts);
             });
         }
     } else {
