@@ -46,6 +46,7 @@ enum { RT_PROJ_ORTHO = 0, RT_PROJ_PERSP = 1 };
 enum { RT_ACCEL_AUTO = 0, RT_ACCEL_BRUTE = 1, RT_ACCEL_LBVH = 2,
        RT_ACCEL_LBVH_PACKET = 3 /* rt_query_rays only: force the wave-packet walk of the LBVH */,
        RT_ACCEL_LBVH_WIDE = 4   /* rt_query_rays only: force the per-lane walk of the 4-wide collapse */,
+       RT_ACCEL_LBVH_TEAM = 5   /* rt_query_rays only: force the walk of the 4-wide collapse by a team of lanes per ray */,
        RT_ACCEL_ALT_TREE = 16   /* rt_query_rays only, OR-ed to an LBVH walk: use the second
                                    hierarchy (PLOC) that rt_load_scene built beside the Karras
                                    one; available until the first render has chosen between them */ };

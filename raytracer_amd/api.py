@@ -20,7 +20,7 @@ RT_OK = 0
  RT_ERR_NO_SCENE) = range(1, 9)
 RT_LIGHT_AMBIENT, RT_LIGHT_DIRECTIONAL, RT_LIGHT_POINT, RT_LIGHT_SPOT = 0, 1, 2, 3
 RT_PROJ_ORTHO, RT_PROJ_PERSP = 0, 1
-RT_ACCEL_AUTO, RT_ACCEL_BRUTE, RT_ACCEL_LBVH, RT_ACCEL_LBVH_PACKET, RT_ACCEL_LBVH_WIDE = 0, 1, 2, 3, 4
+RT_ACCEL_AUTO, RT_ACCEL_BRUTE, RT_ACCEL_LBVH, RT_ACCEL_LBVH_PACKET, RT_ACCEL_LBVH_WIDE, RT_ACCEL_LBVH_TEAM = 0, 1, 2, 3, 4, 5
 RT_ACCEL_ALT_TREE = 16      # query_rays only: OR-ed to an LBVH mode, walks the PLOC hierarchy held until the first render
 RT_PARSE_REF_COMPAT = 1
 RT_TILE = 32

@@ -96,6 +96,7 @@ struct rt_ctx {
     // incoherent ones the per-lane walk); RT_PACKET_GENS / RT_PACKET_SHADOW_GENS force it.
     int8_t mode_extend[RT_MAX_GEN + 1], mode_shadow[RT_MAX_GEN + 1];
     bool tuned = false, forced_modes = false;
+    bool team_walks = true;      // RT_TEAM_WALKS=0: calibration leaves the team walk out
     uint32_t tiles_cap = 0;    // batches of this scene that overflowed a pool that could not grow were split: keep to that size
     bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
     bool stage_times = false;  // HIP events between the stage launches (rt_set_stage_times / RT_STAGE_TIMES)
@@ -159,7 +160,7 @@ static void free_pool(rt_ctx* c) {
     hipFree(c->P.o); hipFree(c->P.d); hipFree(c->P.hp); hipFree(c->P.hn); hipFree(c->P.hd); hipFree(c->P.loc);
     hipFree(c->P.cre); hipFree(c->P.cra); hipFree(c->P.link); hipFree(c->P.wstats); hipFree(c->P.occl); hipFree(c->P.scol);
     hipFree(c->P.mask_hit); hipFree(c->P.mask_refl); hipFree(c->P.mask_refr);
-    hipFree(c->P.child_base); hipFree(c->P.scan_state); hipFree(c->P.hitlist);   // (scan_ticket and wq lie in scan_state's allocation)
+    hipFree(c->P.child_base); hipFree(c->P.scan_state); hipFree(c->P.hitlist); hipFree(c->P.rflag);   // (scan_ticket and wq lie in scan_state's allocation)
     hipFree(c->hp2); hipFree(c->hn2); hipFree(c->hd2); hipFree(c->hitlist2);
     c->hp2 = c->hn2 = c->hd2 = nullptr; c->hitlist2 = nullptr; c->alt_capacity = 0;
     c->P = DPool{};
@@ -183,14 +184,16 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     if (const char* e = getenv("RT_COUNT_WORK")) c->count_work = atoi(e) != 0;
     c->stage_times = getenv("RT_STAGE_TIMES") != nullptr;
     if (const char* e = getenv("RT_OVERLAP_RAYS")) c->overlap_rays = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("RT_TEAM_WALKS")) c->team_walks = atoi(e) != 0;
     if (const char* e = getenv("RT_PACKET_GENS")) {
         c->forced_modes = true;
-        const int lane_mode = getenv("RT_LANE_WIDE") ? 4 : 2;      // RT_LANE_WIDE: the per-lane walks use the 4-wide tree
+        // RT_LANE_WIDE: the other generations walk the 4-wide tree per lane (1) or per team of lanes (2)
+        const int lane_mode = getenv("RT_LANE_WIDE") ? (atoi(getenv("RT_LANE_WIDE")) == 2 ? 5 : 4) : 2;
         for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_extend[g] = g < atoi(e) ? 3 : lane_mode;
     }
     if (const char* e = getenv("RT_PACKET_SHADOW_GENS")) {
         c->forced_modes = true;
-        const int lane_mode = getenv("RT_LANE_WIDE") ? 4 : 2;
+        const int lane_mode = getenv("RT_LANE_WIDE") ? (atoi(getenv("RT_LANE_WIDE")) == 2 ? 5 : 4) : 2;
         for (int g = 0; g <= RT_MAX_GEN; g++) c->mode_shadow[g] = g < atoi(e) ? 3 : lane_mode;
     }
     c->device = c->opt.device;
@@ -486,6 +489,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     c->P.scan_ticket = (uint32_t*)(c->P.scan_state + c->P.scan_words);
     c->P.wq = (uint32_t*)((char*)c->P.scan_ticket + ticket_bytes);
     HIP_TRY(hipMalloc(&c->P.hitlist, capacity * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->P.rflag, (capacity + 63) / 64 * 64));
     HIP_TRY(hipMalloc(&c->P.occl, occl));
     HIP_TRY(hipMalloc(&c->P.scol, samples * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.link, capacity * sizeof(uint32_t)));
@@ -632,8 +636,8 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
         if (c->accel == RT_ACCEL_LBVH) { acc_e = c->mode_extend[g]; acc_s = c->mode_shadow[g]; }
-        if (acc_e == 4 && !S.nodes4) acc_e = 2;
-        if (acc_s == 4 && !S.nodes4) acc_s = 2;
+        if (acc_e >= 4 && !S.nodes4) acc_e = 2;
+        if (acc_s >= 4 && !S.nodes4) acc_s = 2;
         const bool ov = g >= first_ov;
         DPool P = c->P;
         if (any_ov && (g & 1)) { P.hp = c->hp2; P.hn = c->hn2; P.hd = c->hd2; P.hitlist = c->hitlist2; }
@@ -641,7 +645,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         rtk_extend(st, acc_e, S, P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work, c->launch_cache, ov);
         LAUNCH_CHECK("extend", g);
         tm.mark(0);
-        rtk_compact(st, P, c->d_counters, g, bound, c->max_blocks);
+        rtk_compact(st, P, c->d_counters, g, bound, c->max_blocks, acc_e);
         LAUNCH_CHECK("compact", g);
         tm.mark(3);
         const uint64_t items = bound * (uint64_t)std::max(1, S.nl);
@@ -759,7 +763,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
 #define CAL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rt_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return (e_ == hipErrorOutOfMemory) ? RT_ERR_NOMEM : RT_ERR_HIP; } } while (0)
     for (auto& e : ev) CAL_TRY(hipEventCreate(&e));
     // [tree][walk mode][generation], milliseconds
-    struct Times { float v[2][5][RT_MAX_GEN + 1]; };
+    struct Times { float v[2][6][RT_MAX_GEN + 1]; };
     std::vector<Times> times(2);
     auto& te = times[0].v;
     auto& tsh = times[1].v;
@@ -778,10 +782,10 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         ok = true;
         for (int t = 0; t < ntrees && ok; t++) {
             S.nodes = tree_nodes[t]; S.nodes4 = tree_wide[t]; S.depth = tree_depth[t]; S.root = 0;
-            for (int mode = 2; mode <= 4 && ok; mode++) {
+            for (int mode = 2; mode <= 5 && ok; mode++) {
                 // the per-lane walk on the binary tree is timed only where no 4-wide collapse exists: wherever
                 // both were timed the 4-wide one won, and the binary one is the most expensive trial of all
-                if ((mode == 4 && !tree_wide[t]) || (mode == 2 && tree_wide[t])) {
+                if ((mode >= 4 && !tree_wide[t]) || (mode == 2 && tree_wide[t]) || (mode == 5 && !c->team_walks)) {
                     for (int g = 0; g < G; g++) te[t][mode][g] = tsh[t][mode][g] = 1e30f;
                     continue;
                 }
@@ -797,7 +801,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                         hipEventRecord(ev[4 * g + 0], st);
                         rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false, c->launch_cache);
                         hipEventRecord(ev[4 * g + 1], st);
-                        rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks);
+                        rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks, mode);
                         hipEventRecord(ev[4 * g + 2], st);
                         rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false, c->launch_cache);
                         hipEventRecord(ev[4 * g + 3], st);
@@ -828,8 +832,8 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         float best_total[2] = {0, 0};
         for (int t = 0; t < ntrees; t++)
             for (int g = 0; g < G; g++)
-                best_total[t] += std::min(te[t][2][g], std::min(te[t][3][g], te[t][4][g])) +
-                                 std::min(tsh[t][2][g], std::min(tsh[t][3][g], tsh[t][4][g]));
+                best_total[t] += std::min(std::min(te[t][2][g], te[t][5][g]), std::min(te[t][3][g], te[t][4][g])) +
+                                 std::min(std::min(tsh[t][2][g], tsh[t][5][g]), std::min(tsh[t][3][g], tsh[t][4][g]));
         int t = (ntrees == 2 && best_total[1] < best_total[0]) ? 1 : 0;
         if (const char* e = getenv("RT_TREE")) {             // "karras" / "ploc": override the measurement
             if (!strcmp(e, "karras")) t = 0;
@@ -843,22 +847,24 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
         for (int g = 0; g < G; g++) {
             // within 10 % the packet walk is kept: thin generations time within noise of each other, and a
             // choice that flips from run to run would make the work counters (fetches per ray) flip with it
-            auto best_of = [](float lane, float packet, float wide) {
-                return (packet <= 1.1f * lane && packet <= 1.1f * wide) ? 3 : (wide < lane ? 4 : 2);
+            auto best_of = [](float lane, float packet, float wide, float team) {
+                if (packet <= 1.1f * lane && packet <= 1.1f * wide && packet <= 1.1f * team) return 3;
+                if (team < lane && team < wide) return 5;
+                return wide < lane ? 4 : 2;
             };
-            c->mode_extend[g] = (int8_t)best_of(te[t][2][g], te[t][3][g], te[t][4][g]);
-            c->mode_shadow[g] = (int8_t)best_of(tsh[t][2][g], tsh[t][3][g], tsh[t][4][g]);
+            c->mode_extend[g] = (int8_t)best_of(te[t][2][g], te[t][3][g], te[t][4][g], te[t][5][g]);
+            c->mode_shadow[g] = (int8_t)best_of(tsh[t][2][g], tsh[t][3][g], tsh[t][4][g], tsh[t][5][g]);
         }
         if (getenv("RT_VERBOSE")) {
             fprintf(stderr, "[rt calibrate] %u tiles; traversal ms Karras %.3f", n, best_total[0]);
             if (ntrees == 2) fprintf(stderr, ", PLOC %.3f", best_total[1]);
-            const char* tag = "?-LPW";
-            fprintf(stderr, " -> %s; extend (lane/packet/wide ms):", t ? "PLOC" : "Karras");
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, te[t][2][g] > 1e29f ? 0.0f : te[t][2][g], te[t][3][g], te[t][4][g] > 1e29f ? 0.0f : te[t][4][g], tag[c->mode_extend[g]]);
+            const char* tag = "?-LPWT";
+            fprintf(stderr, " -> %s; extend (lane/packet/wide/team ms):", t ? "PLOC" : "Karras");
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f/%.3f->%c", g, te[t][2][g] > 1e29f ? 0.0f : te[t][2][g], te[t][3][g], te[t][4][g] > 1e29f ? 0.0f : te[t][4][g], te[t][5][g] > 1e29f ? 0.0f : te[t][5][g], tag[c->mode_extend[g]]);
             fprintf(stderr, "; rays:");
             for (int g = 0; g < G; g++) fprintf(stderr, " g%d %u", g, sample_rays[g]);
             fprintf(stderr, "; shadow:");
-            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f->%c", g, tsh[t][2][g] > 1e29f ? 0.0f : tsh[t][2][g], tsh[t][3][g], tsh[t][4][g] > 1e29f ? 0.0f : tsh[t][4][g], tag[c->mode_shadow[g]]);
+            for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f/%.3f->%c", g, tsh[t][2][g] > 1e29f ? 0.0f : tsh[t][2][g], tsh[t][3][g], tsh[t][4][g] > 1e29f ? 0.0f : tsh[t][4][g], tsh[t][5][g] > 1e29f ? 0.0f : tsh[t][5][g], tag[c->mode_shadow[g]]);
             fprintf(stderr, "\n");
         }
     } else {
@@ -1208,7 +1214,8 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     if (!c->has_scene) return RT_ERR_NO_SCENE;
     const bool alt = (accel & RT_ACCEL_ALT_TREE) != 0;
     accel &= ~RT_ACCEL_ALT_TREE;
-    if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH && accel != RT_ACCEL_LBVH_PACKET && accel != RT_ACCEL_LBVH_WIDE) return RT_ERR_INVALID;
+    if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH && accel != RT_ACCEL_LBVH_PACKET && accel != RT_ACCEL_LBVH_WIDE &&
+        accel != RT_ACCEL_LBVH_TEAM) return RT_ERR_INVALID;
     if (alt && (accel == RT_ACCEL_BRUTE || !c->d_nodes_alt)) {
         rt_set_error("no second hierarchy is held (none was built, or a render has already chosen)");
         return RT_ERR_UNSUPPORTED;
@@ -1230,7 +1237,7 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     if (dmax) Q_TRY(hipMemcpyAsync(d_m, dmax, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     DScene Sq = c->S;
     if (alt) { Sq.nodes = c->d_nodes_alt; Sq.nodes4 = c->d_wide_alt; Sq.depth = c->depth_alt; Sq.root = 0; }
-    if (accel == RT_ACCEL_LBVH_WIDE && !Sq.nodes4) {
+    if ((accel == RT_ACCEL_LBVH_WIDE || accel == RT_ACCEL_LBVH_TEAM) && !Sq.nodes4) {
         cleanup();
         rt_set_error("no 4-wide collapse of this hierarchy was built (tree deeper than 64)");
         return RT_ERR_UNSUPPORTED;

@@ -137,6 +137,7 @@ struct DPool {
     uint32_t* scan_ticket;
     uint64_t scan_words;
     uint32_t* hitlist;     // compacted: h -> ray index within the generation, in ray order
+    uint8_t* rflag;        // per ray of the current generation, written by extend launches made of team walks instead of the masks: 1 hit | 2 reflects | 4 refracts
     uint8_t* occl;    // [h * nl + light] 1 = in shadow
     float4* scol;     // per sample colour of the batch
     uint32_t capacity;     // rays

@@ -8,8 +8,8 @@
 // Blocks of each traversal kernel that are resident at once on the context's device, by (counting variant,
 // walk): filled on first use from the occupancy query, kept per context because it is a property of the device.
 struct RtkLaunchCache {
-    int extend[2][5] = {{0}};
-    int shadow[2][5] = {{0}};
+    int extend[2][6] = {{0}};
+    int shadow[2][6] = {{0}};
 };
 
 void rtk_init_counters(hipStream_t st, DCounters* C, uint32_t nsamples, const DPool& P, int generations, bool count_work);
@@ -19,7 +19,8 @@ void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
                 RtkLaunchCache& cache, bool defer_miss = false);
 // prefix sums over the wave masks of generation g: hit list, hit / next-generation counts, child offsets
 void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C);
-void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks);
+// extend_accel: the walk of the extend launch before it (5 = team walks leave flag bytes, not masks)
+void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks, int extend_accel);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks, bool count, RtkLaunchCache& cache);
 // phase 0: lights + hand-over + spawn; 1: spawn only; 2: lights + hand-over only (overlapped pipeline)

@@ -34,10 +34,13 @@
 // a vector register written with v_writelane, and a spill of it under a partial EXEC mask would lose entries.
 // Their counting variants carry more live values, so they settle for 5 waves (measurement only); the build
 // fails if any packet kernel uses scratch memory (tools/isa_stats.py --check).
-#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : (ACCEL == 3 ? (COUNT ? RT_PACKET_WAVES - 1 : RT_PACKET_WAVES) : 1), 8)))
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((ACCEL == 2 || ACCEL == 4) ? RT_LANE_WAVES : ACCEL == 5 ? RT_TEAM_WAVES : (ACCEL == 3 ? (COUNT ? RT_PACKET_WAVES - 1 : RT_PACKET_WAVES) : 1), 8)))
 #endif
 #ifndef RT_LANE_WAVES
 #define RT_LANE_WAVES 5
+#endif
+#ifndef RT_TEAM_WAVES
+#define RT_TEAM_WAVES 4
 #endif
 #ifndef RT_PACKET_WAVES
 #define RT_PACKET_WAVES 6
@@ -618,6 +621,189 @@ __device__ __forceinline__ void trace(const DScene& S, float4* lds, bool active,
     else lbvh_trace_packet<ANY>(S, active, o, d, dmax, best, best_d2, uv, ts);
 }
 
+// ---------------------------------------------------------------- team walk (a ray per TEAM of lanes)
+// A launch with few rays ends when its LONGEST walk does: a ray that grazes through a hedge visits hundreds
+// of nodes, one dependent fetch after the other, while the chip stands all but empty.  Here T lanes walk ONE ray
+// on the 4-wide tree: every round the team takes up to T / 4 node references off its stack (in LDS) and each
+// lane tests one child box; a child that is hit and is a leaf gets its exact test at once, in the same lane, one
+// that is an inner node goes on the stack -- entries in the order a depth-first walk would visit them (children
+// of the entry that was on top end up on top, nearest last).  A walk of N steps becomes about depth + N / (T / 4)
+// rounds.  The team looks at boxes a depth-first walk would have culled after a nearer hit; the hit it reports
+// is the same (distance, primitive id) lexicographic minimum over the same exact tests.  A stack that would
+// outgrow its LDS slice (TEAM_STACK entries; past three quarters the team takes one entry per round, which is a
+// depth-first walk) hands the ray to the private-stack walk.
+#ifndef TEAM_T
+#define TEAM_T 16           // closest-hit walks
+#endif
+#ifndef TEAM_TS
+#define TEAM_TS 8           // any-hit walks: many short rays, and nothing to reduce over the team
+#endif
+#define TEAM_STACK 96
+#define TEAM_LDS_INTS ((64 / (TEAM_T < TEAM_TS ? TEAM_T : TEAM_TS)) * TEAM_STACK)          // per wave
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {            // v of the lane CTRL names (quad_perm / row rotation)
+    return bitsf((uint32_t)__builtin_amdgcn_update_dpp(0, (int)fbits(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+#define DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define DPP_QUAD_XOR3 0x1B      // quad_perm [3,2,1,0]
+#define DPP_ROW_ROR(n) (0x120 + (n))
+
+template <int T>
+__device__ __forceinline__ float team_min(float m) {        // every lane of the team gets the minimum
+    m = fminf(m, dpp_f<DPP_QUAD_XOR1>(m));
+    m = fminf(m, dpp_f<DPP_QUAD_XOR2>(m));
+    m = fminf(m, dpp_f<DPP_ROW_ROR(4)>(m));                  // rotations inside the 16-lane row
+    m = fminf(m, dpp_f<DPP_ROW_ROR(8)>(m));
+    if (T >= 32) m = fminf(m, __shfl_xor(m, 16));
+    if (T >= 64) m = fminf(m, __shfl_xor(m, 32));
+    return m;
+}
+
+// All 64 lanes call; the lanes of a team pass the same ray.  Every lane of the team returns the result.
+template <bool ANY, int T>
+__device__ __forceinline__ void team_walk(const DScene& S, int* wave_stack, bool active, F3 o, F3 d, float dmax, int& best,
+                                          float& best_d2, HitUV& uv, TraceStats& ts) {
+    static_assert(T == 16 || T == 32 || T == 64 || (ANY && (T == 4 || T == 8)), "a team is one, two or four 16-lane rows (any-hit walks, which reduce nothing: also 4 or 8 lanes)");
+    constexpr int PMAX = T / 4;
+    const uint32_t lane = threadIdx.x & 63u, tl = lane & (uint32_t)(T - 1), team = lane / (uint32_t)T;
+    const int e = (int)(tl >> 2), c = (int)(tl & 3u);
+    int* stk = wave_stack + team * TEAM_STACK;
+    const unsigned long long team_bits = (T == 64) ? ~0ull : ((1ull << (T & 63)) - 1ull);
+    const int team_shift = (int)(team * (uint32_t)T);
+    const double dd = (double)dot3(d, d);
+    const SlabRay R = slab_ray(o, d);
+    float tmax = slab_tmax(R, dmax);
+    int sp = active ? 1 : 0;
+    if (active && tl == 0) stk[0] = 0;                        // both trees keep their root at node 0
+    int cb = -1; float cd2 = dmax; HitUV cuv; cuv.a = 0; cuv.b = 0;      // this lane's best candidate
+    bool redo = false, shadowed = false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    while (ballot64(sp > 0) != 0ull) {
+        const int npop = sp > TEAM_STACK - 4 * PMAX ? 1 : (sp < PMAX ? sp : PMAX);
+        const bool has = e < npop;
+        const int node = has ? stk[sp - 1 - e] : 0;
+        sp -= npop;
+        bool hit = false;
+        float tn = 0;
+        int ref = LANE_DONE;
+        if (has) {
+            v2f tx, ty, tz;
+            if (S.wide_quant) {
+                const v4f* nd = (const v4f*)S.nodes4 + 4 * (size_t)node;
+                const v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                const uint32_t eb = fbits(q0.w);
+                const float ax = bitsf((eb & 0xFFu) << 23) * R.inv.x, ay = bitsf(((eb >> 8) & 0xFFu) << 23) * R.inv.y,
+                            az = bitsf(((eb >> 16) & 0xFFu) << 23) * R.inv.z;
+                const float bx = __builtin_fmaf(q0.x, R.inv.x, R.noi.x), by = __builtin_fmaf(q0.y, R.inv.y, R.noi.y),
+                            bz = __builtin_fmaf(q0.z, R.inv.z, R.noi.z);
+                const int sh = 8 * c;
+                tx = (v2f){__builtin_fmaf((float)((fbits(q1.x) >> sh) & 0xFFu), ax, bx), __builtin_fmaf((float)((fbits(q1.w) >> sh) & 0xFFu), ax, bx)};
+                ty = (v2f){__builtin_fmaf((float)((fbits(q1.y) >> sh) & 0xFFu), ay, by), __builtin_fmaf((float)((fbits(q2.x) >> sh) & 0xFFu), ay, by)};
+                tz = (v2f){__builtin_fmaf((float)((fbits(q1.z) >> sh) & 0xFFu), az, bz), __builtin_fmaf((float)((fbits(q2.y) >> sh) & 0xFFu), az, bz)};
+                ref = (int)fbits(c == 0 ? q2.z : c == 1 ? q2.w : c == 2 ? q3.x : q3.y);
+                if (c == 0) ts.nodes += 1;
+            } else {
+                const float* nf = (const float*)S.nodes4 + 32 * (size_t)node;
+                const float2* bx = (const float2*)(nf + 6 * c);
+                const float2 x = bx[0], y = bx[1], z = bx[2];
+                ref = __float_as_int(nf[24 + c]);
+                tx = (v2f){__builtin_fmaf(x.x, R.inv.x, R.noi.x), __builtin_fmaf(x.y, R.inv.x, R.noi.x)};
+                ty = (v2f){__builtin_fmaf(y.x, R.inv.y, R.noi.y), __builtin_fmaf(y.y, R.inv.y, R.noi.y)};
+                tz = (v2f){__builtin_fmaf(z.x, R.inv.z, R.noi.z), __builtin_fmaf(z.y, R.inv.z, R.noi.z)};
+                if (c == 0) ts.nodes += 2;
+            }
+            if (c == 0) ts.lane_nodes += 2;
+            hit = slab_hit<8>(tx, ty, tz, tmax, tn) && ref != LANE_DONE;
+        }
+        // children that are leaves: the exact test now, in the lane that holds the child
+        const bool at_leaf = hit && ref < 0;
+        unsigned long long done_any = 0ull;
+#ifdef TEAM_DEBUG
+        if (has && blockIdx.x == 0 && threadIdx.x < 16) printf("ANY %d lane %d sp(after pop) %d npop %d node %d c %d ref %d hit %d tn %g tmax %g\n", (int)ANY, (int)lane, sp, npop, node, c, ref, (int)hit, tn, tmax);
+#endif
+        if (ballot64(at_leaf) != 0ull) {
+            if (at_leaf) {
+                const float4* lf = S.leaf + 3 * (size_t)(~ref);
+                const float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
+                const int prim = (int)fbits(l2.y);
+                if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
+                ts.lane_prims++;
+                float d2 = 0;
+                HitUV cand;
+#ifdef TEAM_DEBUG
+                bool lt = leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand);
+                if (blockIdx.x == 0 && threadIdx.x < 16) printf("  leaf lane %d prim %d -> %d d2 %g dmax %g\n", (int)lane, prim, (int)lt, d2, dmax);
+#endif
+                if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand)) {
+                    if (ANY) shadowed = true;
+                    else if (cb < 0 || d2 < cd2 || (d2 == cd2 && prim < cb)) { cb = prim; cd2 = d2; cuv = cand; }
+                }
+            }
+            if (ANY) done_any = ballot64(shadowed);
+            else tmax = slab_tmax(R, team_min<T>(cd2));
+        }
+        const bool team_done = ANY && ((done_any >> team_shift) & team_bits) != 0ull;
+        // children that are inner nodes go on the stack
+        const bool push = hit && ref >= 0 && !team_done;
+        const unsigned long long pm = ballot64(push);
+        if (team_done) sp = 0;
+        if (pm != 0ull) {
+            const unsigned long long tb = (pm >> team_shift) & team_bits;       // this team's pushing lanes
+            const uint32_t quad = (uint32_t)(tb >> (4 * e)) & 0xFu;
+            const int above = __popcll((tb >> (4 * e)) >> 4);                    // pushed by entries deeper in the stack: they go first
+            const float t1 = dpp_f<DPP_QUAD_XOR1>(tn), t2 = dpp_f<DPP_QUAD_XOR2>(tn), t3 = dpp_f<DPP_QUAD_XOR3>(tn);
+            const int c1 = c ^ 1, c2 = c ^ 2, c3 = c ^ 3;
+            int farther = 0;                                                     // of my own node's children: farther ones first
+            farther += ((quad >> c1) & 1u) && (t1 > tn || (t1 == tn && c1 > c));
+            farther += ((quad >> c2) & 1u) && (t2 > tn || (t2 == tn && c2 > c));
+            farther += ((quad >> c3) & 1u) && (t3 > tn || (t3 == tn && c3 > c));
+            const int pos = sp + above + farther;
+            bool over = false;
+            if (push) {
+                if (pos < TEAM_STACK) stk[pos] = ref;
+                else over = true;
+            }
+            sp += __popcll(tb);
+            const unsigned long long ov = ballot64(over);
+            if (((ov >> team_shift) & team_bits) != 0ull) { sp = 0; redo = true; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (ANY) {
+#ifdef TEAM_DEBUG
+        if (blockIdx.x == 0 && threadIdx.x < 4) printf("end lane %d shadowed %d ballot %llx shift %d bits %llx\n", (int)lane, (int)shadowed, ballot64(shadowed), team_shift, team_bits);
+#endif
+        const unsigned long long sm = ballot64(shadowed);         // (by every lane: not behind a short-circuit)
+        best = ((sm >> team_shift) & team_bits) != 0ull ? 0 : -1;
+        best_d2 = 0;
+        uv.a = 0; uv.b = 0;
+    } else {
+        // lexicographic minimum of the lanes' candidates; rotations inside the 16-lane row, then across rows
+        auto take = [&](int ob, float od2, float oa, float obb) {
+            if (ob >= 0 && (cb < 0 || od2 < cd2 || (od2 == cd2 && ob < cb))) { cb = ob; cd2 = od2; cuv.a = oa; cuv.b = obb; }
+        };
+        take(dpp_i<DPP_QUAD_XOR1>(cb), dpp_f<DPP_QUAD_XOR1>(cd2), dpp_f<DPP_QUAD_XOR1>(cuv.a), dpp_f<DPP_QUAD_XOR1>(cuv.b));
+        take(dpp_i<DPP_QUAD_XOR2>(cb), dpp_f<DPP_QUAD_XOR2>(cd2), dpp_f<DPP_QUAD_XOR2>(cuv.a), dpp_f<DPP_QUAD_XOR2>(cuv.b));
+        take(dpp_i<DPP_ROW_ROR(4)>(cb), dpp_f<DPP_ROW_ROR(4)>(cd2), dpp_f<DPP_ROW_ROR(4)>(cuv.a), dpp_f<DPP_ROW_ROR(4)>(cuv.b));
+        take(dpp_i<DPP_ROW_ROR(8)>(cb), dpp_f<DPP_ROW_ROR(8)>(cd2), dpp_f<DPP_ROW_ROR(8)>(cuv.a), dpp_f<DPP_ROW_ROR(8)>(cuv.b));
+        if (T >= 32) take(__shfl_xor(cb, 16), __shfl_xor(cd2, 16), __shfl_xor(cuv.a, 16), __shfl_xor(cuv.b, 16));
+        if (T >= 64) take(__shfl_xor(cb, 32), __shfl_xor(cd2, 32), __shfl_xor(cuv.a, 32), __shfl_xor(cuv.b, 32));
+        best = cb; best_d2 = cd2; uv = cuv;
+    }
+    if (ballot64(redo) != 0ull) {
+        // the stack outgrew its slice (rare): this ray again, one lane, stack in private memory
+        int b; float bd; HitUV buv;
+        lbvh_trace<ANY, true>(S, redo && tl == 0, o, d, dmax, b, bd, buv, ts);
+        const int src = (int)(lane - tl);
+        const int rb = __shfl(b, src); const float rd2 = __shfl(bd, src), ra = __shfl(buv.a, src), rbb = __shfl(buv.b, src);
+        if (redo) { best = rb; best_d2 = rd2; uv.a = ra; uv.b = rbb; }
+    }
+}
+
 // Work counters of a traversal launch.  Every wave adds its totals to a slot of its own
 // (plain loads and stores: the slot belongs to this wave id for the launch, and launches
 // of a batch follow one another), and one small kernel sums the slots at the end of the
@@ -838,6 +1024,41 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
     }
 }
 
+// extend_one for a launch whose walks are team walks: the wave owns the 64 / T consecutive rays of `item`, one
+// per team; lane 0 of each team writes the ray's record.  The three ballot masks of a 64-ray group cannot be put
+// together by one wave here (a group is spread over T waves): each ray leaves a flag byte (P.rflag: 1 hit,
+// 2 spawns a reflection ray, 4 a refraction ray) and the scan kernel builds the masks from the bytes.
+template <int T>
+__device__ __forceinline__ void extend_team(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
+                                            uint32_t count, uint64_t item, int* wave_stack, TraceStats& ts) {
+    const uint32_t lane = threadIdx.x & 63u, tl = lane & (uint32_t)(T - 1), team = lane / (uint32_t)T;
+    const uint64_t i64 = item * (uint64_t)(64 / T) + team;
+    const bool inrange = i64 < (uint64_t)count;
+    const uint32_t i = inrange ? (uint32_t)i64 : 0u;
+    RayRec R = load_ray(P, G, g, i, start + i);
+    const bool active = inrange && R.valid;
+    int best; float best_d2; HitUV uv;
+    team_walk<false, T>(S, wave_stack, active, R.o, R.d, __builtin_inff(), best, best_d2, uv, ts);
+    if (tl != 0 || !inrange) return;
+    uint32_t bits = 0;
+    if (active && best >= 0) {
+        F3 point, normal; int mat;
+        make_hit_uv(S, R.o, R.d, best, uv, point, normal, mat);
+        P.hp[i] = make_float4(point.x, point.y, point.z, bitsf((uint32_t)best));
+        P.hn[i] = make_float4(normal.x, normal.y, normal.z, bitsf((uint32_t)mat | (R.slot << 31)));
+        P.hd[i] = make_float4(R.d.x, R.d.y, R.d.z, bitsf(R.parent));
+        bits = 1;
+        if (g + 1 <= S.max_depth) {   // deeper children are never traced (src/raytrace.cpp:132-135)
+            const float4* M = S.mats + 4 * (size_t)mat;
+            Spawn sp = spawn_of(f3(M[2]), f3(M[3]), M[1].w, R.d, normal);
+            bits |= (sp.refl ? 2u : 0u) | (sp.refr ? 4u : 0u);
+        }
+    } else if (active && !(G.defer_miss && g > 0)) {
+        deliver(S, P, g, R.parent, R.slot, S.bg);
+    }
+    P.rflag[i] = (uint8_t)bits;
+}
+
 #ifndef REFILL_GROUPS
 #define REFILL_GROUPS 8
 #endif
@@ -966,7 +1187,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
 
 template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : ACCEL == 5 ? TEAM_LDS_INTS * (RT_BLOCK / 64) / 4 : 1];
     if (C->overflow) return;   // ray slots past an overflow were never written: the host re-runs the batch
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
@@ -993,6 +1214,11 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
                 extend_chunk<ACCEL == 4>(S, P, G, g, start, gbase, first, min(span, count - first), flags[threadIdx.x >> 6], (int*)lds, ts);
             });
         }
+    } else if (ACCEL == 5) {
+        constexpr uint64_t per_wave = 64 / TEAM_T;
+        for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + per_wave - 1) / per_wave, [&](uint64_t item) {
+            extend_team<TEAM_T>(S, P, G, g, start, count, item, (int*)lds + (threadIdx.x >> 6) * TEAM_LDS_INTS, ts);
+        });
     } else {
         for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + 63) >> 6, [&](uint64_t grp) {
             extend_one<ACCEL>(S, P, G, g, start, count, gbase, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
@@ -1049,7 +1275,7 @@ __device__ __forceinline__ uint2 block_scan(uint2 v, uint2* lds /*[SCAN_BLOCK]*/
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)           // most groups per block and state word: 2048 = 131072 rays
 #define SCAN_TILES_WANTED 1024u
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(DPool P, DCounters* C, int g) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(DPool P, DCounters* C, int g, int from_flags) {
     __shared__ uint2 lds[SCAN_BLOCK];
     __shared__ uint32_t hb[SCAN_TILE];
     __shared__ unsigned long long hm[SCAN_TILE];
@@ -1081,12 +1307,57 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(DPool P, DCounters* C, int 
         for (uint32_t k = threadIdx.x; k < tile; k += SCAN_BLOCK) {
             unsigned long long mh = 0ull;
             uint32_t kids = 0;
-            if (k < ng) {
+            if (k < ng && !from_flags) {
                 mh = P.mask_hit[gbase + first + k];
                 kids = (uint32_t)(__popcll(P.mask_refl[gbase + first + k]) + __popcll(P.mask_refr[gbase + first + k]));
             }
-            hm[k] = mh;
-            hb[k] = kids;
+            if (!from_flags || k >= ng) {                 // (with flags the slots of real groups are written below)
+                hm[k] = mh;
+                hb[k] = kids;
+            }
+        }
+        if (from_flags) {
+            // The extend launch left one flag byte per ray (team walks), not masks: build the three masks of every
+            // group here and keep them for the shade kernels.  A lane takes 16 consecutive bytes (one load), four
+            // neighbouring lanes make a group: bit b of four bytes at once is (x >> b & 0x01010101) * 0x10204080
+            // >> 28, the quarters meet through quad shuffles.  Coalesced: a wave reads 1 KiB = 16 groups per load.
+            const uint32_t q = threadIdx.x & 3u;
+            for (uint32_t k4 = threadIdx.x; k4 < tile * 4u; k4 += SCAN_BLOCK) {
+                const uint32_t k = k4 >> 2;
+                const bool in = k < ng;
+                uint4 w = make_uint4(0, 0, 0, 0);
+                if (in) w = ((const uint4*)(P.rflag + ((size_t)(first + k) << 6)))[q];
+                const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+                uint32_t p0 = 0, p1 = 0, p2 = 0;                 // 16 bits each: this lane's quarter of the masks
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    p0 |= (((x[t] & 0x01010101u) * 0x10204080u) >> 28) << (4 * t);
+                    p1 |= ((((x[t] >> 1) & 0x01010101u) * 0x10204080u) >> 28) << (4 * t);
+                    p2 |= ((((x[t] >> 2) & 0x01010101u) * 0x10204080u) >> 28) << (4 * t);
+                }
+                // halves of the 64-bit masks: quarters 0, 1 -> low word, 2, 3 -> high word
+                uint32_t lo0 = q < 2u ? p0 << (16 * q) : 0u, hi0 = q >= 2u ? p0 << (16 * (q - 2u)) : 0u;
+                uint32_t lo1 = q < 2u ? p1 << (16 * q) : 0u, hi1 = q >= 2u ? p1 << (16 * (q - 2u)) : 0u;
+                uint32_t lo2 = q < 2u ? p2 << (16 * q) : 0u, hi2 = q >= 2u ? p2 << (16 * (q - 2u)) : 0u;
+                lo0 |= (uint32_t)dpp_i<DPP_QUAD_XOR1>((int)lo0); hi0 |= (uint32_t)dpp_i<DPP_QUAD_XOR1>((int)hi0);
+                lo1 |= (uint32_t)dpp_i<DPP_QUAD_XOR1>((int)lo1); hi1 |= (uint32_t)dpp_i<DPP_QUAD_XOR1>((int)hi1);
+                lo2 |= (uint32_t)dpp_i<DPP_QUAD_XOR1>((int)lo2); hi2 |= (uint32_t)dpp_i<DPP_QUAD_XOR1>((int)hi2);
+                lo0 |= (uint32_t)dpp_i<DPP_QUAD_XOR2>((int)lo0); hi0 |= (uint32_t)dpp_i<DPP_QUAD_XOR2>((int)hi0);
+                lo1 |= (uint32_t)dpp_i<DPP_QUAD_XOR2>((int)lo1); hi1 |= (uint32_t)dpp_i<DPP_QUAD_XOR2>((int)hi1);
+                lo2 |= (uint32_t)dpp_i<DPP_QUAD_XOR2>((int)lo2); hi2 |= (uint32_t)dpp_i<DPP_QUAD_XOR2>((int)hi2);
+                if (in && q == 0u) {
+                    unsigned long long mh = ((unsigned long long)hi0 << 32) | lo0, m1 = ((unsigned long long)hi1 << 32) | lo1,
+                                       m2 = ((unsigned long long)hi2 << 32) | lo2;
+                    const uint32_t left = count - ((first + k) << 6);      // rays of the group (the last one may be short:
+                    if (left < 64u) {                                      //  nobody wrote the bytes past the generation's end)
+                        const unsigned long long keep = (1ull << left) - 1ull;
+                        mh &= keep; m1 &= keep; m2 &= keep;
+                    }
+                    P.mask_hit[gbase + first + k] = mh; P.mask_refl[gbase + first + k] = m1; P.mask_refr[gbase + first + k] = m2;
+                    hm[k] = mh;
+                    hb[k] = (uint32_t)(__popcll(m1) + __popcll(m2));
+                }
+            }
         }
         __syncthreads();
         uint32_t eh[SCAN_ITEMS], ek[SCAN_ITEMS];
@@ -1249,7 +1520,7 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, in
 // around their common origin.)
 template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPool P, DCounters* C, int g) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : ACCEL == 5 ? TEAM_LDS_INTS * (RT_BLOCK / 64) / 4 : 1];
     if (C->overflow) return;
     const uint32_t nh = C->hit_count[g];
     const uint64_t items = (uint64_t)nh * (uint64_t)S.nl;
@@ -1284,6 +1555,22 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
                 shadow_chunk<ACCEL == 4>(S, P, (int*)lds, first, first + span < items ? first + span : items, ts);
             });
         }
+    } else if (ACCEL == 5) {
+        // team walks: the wave owns 64 / T consecutive items, one per team
+        constexpr uint64_t per_wave = 64 / TEAM_TS;
+        const uint32_t lane = threadIdx.x & 63u;
+        for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + per_wave - 1) / per_wave, [&](uint64_t pk) {
+            const uint64_t k = pk * per_wave + lane / TEAM_TS;
+            const bool active = k < items;
+            const uint32_t h = active ? (uint32_t)(k / (uint32_t)S.nl) : 0;
+            const int j = active ? (int)(k - (uint64_t)h * (uint32_t)S.nl) : 0;
+            const F3 point = f3(P.hp[P.hitlist[h]]);
+            F3 I; float dist2;
+            light_dir(S.lights[j], point, I, dist2);
+            int best; float best_d2; HitUV uv;
+            team_walk<true, TEAM_TS>(S, (int*)lds + (threadIdx.x >> 6) * TEAM_LDS_INTS, active, point, I, dist2, best, best_d2, uv, ts);
+            if (active && (lane & (TEAM_TS - 1)) == 0) P.occl[k] = (best >= 0) ? 1 : 0;
+        });
     } else {
         for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + 63) >> 6,
                        [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });
@@ -1548,8 +1835,33 @@ __global__ void k_rowbase(int world, int ntx, int nty, uint32_t* rowbase) {
 template <int ACCEL, bool ANY>
 __global__ __launch_bounds__(RT_BLOCK) void k_query(DScene S, int64_t n, const float* o, const float* d,
                                                     const float* dmax, int* prim_out, float* d2_out) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : ACCEL == 5 ? TEAM_LDS_INTS * (RT_BLOCK / 64) / 4 : 1];
     TraceStats ts;
+    if (ACCEL == 5) {
+        // team walks: a wave takes its 64 rays 64 / T at a time, one per team
+        constexpr int per = 64 / TEAM_T;
+        const int lane = (int)(threadIdx.x & 63u), team = lane / TEAM_T;
+        for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 64 * 64; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+            for (int pass = 0; pass < TEAM_T; pass++) {
+                const int64_t i = base + (int64_t)pass * per + team;
+                const bool active = i < n;
+                const int64_t ii = active ? i : 0;
+                F3 ro = f3(o[3 * ii], o[3 * ii + 1], o[3 * ii + 2]);
+                F3 rd = f3(d[3 * ii], d[3 * ii + 1], d[3 * ii + 2]);
+                float dm = dmax ? dmax[ii] : __builtin_inff();
+                int best; float best_d2; HitUV uv;
+                team_walk<ANY, TEAM_T>(S, (int*)lds + (threadIdx.x >> 6) * TEAM_LDS_INTS, active, ro, rd, dm, best, best_d2, uv, ts);
+#ifdef TEAM_DEBUG
+                if (blockIdx.x == 0 && threadIdx.x < 4) printf("query lane %d pass %d best %d active %d\n", lane, pass, best, (int)active);
+#endif
+                if (active && (lane & (TEAM_T - 1)) == 0) {
+                    prim_out[i] = best;
+                    if (d2_out) d2_out[i] = best >= 0 ? best_d2 : __builtin_inff();
+                }
+            }
+        }
+        return;
+    }
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
         int64_t i = base + threadIdx.x;
         bool active = i < n;
@@ -1599,11 +1911,13 @@ static void launch_extend(hipStream_t st, int accel, const DScene& S, const DPoo
     if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_extend<1, COUNT>, max_blocks)
                                  : accel == 2 ? resident_blocks(k_extend<2, COUNT>, max_blocks)
                                  : accel == 4 ? resident_blocks(k_extend<4, COUNT>, max_blocks)
+                                 : accel == 5 ? resident_blocks(k_extend<5, COUNT>, max_blocks)
                                               : resident_blocks(k_extend<3, COUNT>, max_blocks);
-    dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
+    dim3 grid(grid_for(accel == 5 ? bound * TEAM_T : bound, res[accel])), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL((k_extend<1, COUNT>), grid, block, 0, st, S, P, C, G, g);
     else if (accel == 2) hipLaunchKernelGGL((k_extend<2, COUNT>), grid, block, 0, st, S, P, C, G, g);
     else if (accel == 4) hipLaunchKernelGGL((k_extend<4, COUNT>), grid, block, 0, st, S, P, C, G, g);
+    else if (accel == 5) hipLaunchKernelGGL((k_extend<5, COUNT>), grid, block, 0, st, S, P, C, G, g);
     else hipLaunchKernelGGL((k_extend<3, COUNT>), grid, block, 0, st, S, P, C, G, g);
 }
 void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, const DCamera& cam,
@@ -1613,11 +1927,11 @@ void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
     if (count || S.profile) launch_extend<true>(st, accel, S, P, C, G, g, bound, max_blocks, cache.extend[1]);
     else launch_extend<false>(st, accel, S, P, C, G, g, bound, max_blocks, cache.extend[0]);
 }
-void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {
+void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks, int extend_accel) {
     uint64_t groups = (bound + 63) / 64;
     int blocks = (int)std::min<uint64_t>((groups + SCAN_BLOCK - 1) / SCAN_BLOCK, (uint64_t)std::min<int>(max_blocks, (int)SCAN_TILES_WANTED));
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_scan, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g);
+    hipLaunchKernelGGL(k_scan, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g, extend_accel == 5 ? 1 : 0);
 }
 template <bool COUNT>
 static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
@@ -1625,11 +1939,13 @@ static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPoo
     if (!res[accel]) res[accel] = accel == 1 ? resident_blocks(k_shadow<1, COUNT>, max_blocks)
                                  : accel == 2 ? resident_blocks(k_shadow<2, COUNT>, max_blocks)
                                  : accel == 4 ? resident_blocks(k_shadow<4, COUNT>, max_blocks)
+                                 : accel == 5 ? resident_blocks(k_shadow<5, COUNT>, max_blocks)
                                               : resident_blocks(k_shadow<3, COUNT>, max_blocks);
-    dim3 grid(grid_for(bound, res[accel])), block(RT_BLOCK);
+    dim3 grid(grid_for(accel == 5 ? bound * TEAM_TS : bound, res[accel])), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL((k_shadow<1, COUNT>), grid, block, 0, st, S, P, C, g);
     else if (accel == 2) hipLaunchKernelGGL((k_shadow<2, COUNT>), grid, block, 0, st, S, P, C, g);
     else if (accel == 4) hipLaunchKernelGGL((k_shadow<4, COUNT>), grid, block, 0, st, S, P, C, g);
+    else if (accel == 5) hipLaunchKernelGGL((k_shadow<5, COUNT>), grid, block, 0, st, S, P, C, g);
     else hipLaunchKernelGGL((k_shadow<3, COUNT>), grid, block, 0, st, S, P, C, g);
 }
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
@@ -1684,6 +2000,9 @@ void rtk_query(hipStream_t st, int accel, int any_hit, const DScene& S, int64_t 
     } else if (accel == 4) {
         if (any_hit) hipLaunchKernelGGL((k_query<4, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
         else hipLaunchKernelGGL((k_query<4, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+    } else if (accel == 5) {
+        if (any_hit) hipLaunchKernelGGL((k_query<5, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
+        else hipLaunchKernelGGL((k_query<5, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
     } else {
         if (any_hit) hipLaunchKernelGGL((k_query<3, true>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);
         else hipLaunchKernelGGL((k_query<3, false>), grid, block, 0, st, S, n, o, d, dmax, prim_out, d2_out);

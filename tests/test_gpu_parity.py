@@ -155,10 +155,10 @@ def test_primary_rays_and_closest_hits_known_answers(oracle, tracer, kat, key, s
         assert np.array_equal(d2[hit].astype(np.float64), ref_hit[hit, 4])   # reference dist (squared)
 
 
-# every walk of every hierarchy: per-lane / packet / per-lane 4-wide, on the Karras and on the PLOC tree
-TREE_WALKS = (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE,
+# every walk of every hierarchy: per-lane / packet / per-lane 4-wide / team of lanes per ray, on the Karras and on the PLOC tree
+TREE_WALKS = (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_TEAM,
               ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_PACKET | ra.RT_ACCEL_ALT_TREE,
-              ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE)
+              ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_TEAM | ra.RT_ACCEL_ALT_TREE)
 
 
 def _random_rays(scene, n, rng):
@@ -217,7 +217,8 @@ def test_quantised_wide_nodes_equal_brute_force(monkeypatch, name):
         dmax = np.where(rng.random(len(o)) < 0.5, db * rng.uniform(0.5, 1.5, len(o)).astype(np.float32), np.float32(np.inf)).astype(np.float32)
         dmax[~np.isfinite(dmax)] = np.inf
         ab, _ = t.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_BRUTE)
-        for accel in (ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE):
+        for accel in (ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE,
+                      ra.RT_ACCEL_LBVH_TEAM, ra.RT_ACCEL_LBVH_TEAM | ra.RT_ACCEL_ALT_TREE):
             pl, dl = t.query_rays(o, d, accel=accel)
             assert np.array_equal(pb, pl), f"accel {accel}: {(pb != pl).sum()} closest hits differ"
             assert np.array_equal(bits(db), bits(dl))
@@ -330,16 +331,16 @@ def test_both_hierarchies_render_the_same_image(tracer, monkeypatch):
                                      ("plant_h_smooth", dict(width=165, height=128, spp=1, max_depth=8)),
                                      ("outdoor_spot", dict(width=200, height=120, spp=2))])
 def test_every_walk_renders_the_same_image(tracer, monkeypatch, name, kw):
-    """Per-lane walks everywhere, packet walks everywhere, brute force: one image, bit for bit."""
+    """Per-lane walks everywhere, team walks everywhere, packet walks everywhere, brute force: one image, bit for bit."""
     scene = load_scene(name).copy(**kw)
     tracer.load_scene(scene)
     rgb0, f0, st0 = tracer.render(want_float=True)
     images = {}
-    for label, n, wide in (("lane", "0", False), ("lane-wide", "0", True), ("packet", "99", False)):
+    for label, n, wide in (("lane", "0", 0), ("lane-wide", "0", 1), ("team", "0", 2), ("packet-then-team", "1", 2), ("packet", "99", 0)):
         monkeypatch.setenv("RT_PACKET_GENS", n)
         monkeypatch.setenv("RT_PACKET_SHADOW_GENS", n)
         if wide:
-            monkeypatch.setenv("RT_LANE_WIDE", "1")
+            monkeypatch.setenv("RT_LANE_WIDE", str(wide))
         with ra.Tracer(device=0, accel=ra.RT_ACCEL_LBVH) as t:
             t.load_scene(scene)
             images[label] = t.render(want_float=True)
