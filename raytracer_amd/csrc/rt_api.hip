@@ -767,7 +767,8 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     std::vector<Times> times(2);
     auto& te = times[0].v;
     auto& tsh = times[1].v;
-    uint32_t sample_rays[RT_MAX_GEN + 1] = {0};      // rays per generation of the sample (for the verbose line)
+    uint32_t sample_rays[RT_MAX_GEN + 1] = {0};      // rays per generation of the sample (known once the first trial has run)
+    bool team_timed[RT_MAX_GEN + 1] = {false};
     bool ok = false;
     // at most 32 Mi samples: enough to be in the throughput regime, and about one extra K3 frame in all
     uint32_t n = std::min(total, std::max(1u, std::min<uint32_t>(tiles_per_batch, (uint32_t)std::max<uint64_t>(1, (32ull << 20) / per_tile))));
@@ -793,17 +794,27 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                 // on the thinnest frames -- the two walks are within a few per cent there -- and the first frame trebles)
                 const int reps = 1;
                 for (int g = 0; g < G; g++) te[t][mode][g] = tsh[t][mode][g] = 1e30f;
+                if (mode == 5) {
+                    bool any_thin = false;
+                    for (int g = 0; g < G; g++) any_thin = any_thin || sample_rays[g] <= (1u << 20);
+                    if (!any_thin) continue;
+                }
                 for (int rep = 0; rep < reps && ok; rep++) {
                     hipStream_t st = c->stream;
                     rtk_init_counters(st, c->d_counters, nsamples, c->P, G, false);
                     uint64_t bound = nsamples;
                     for (int g = 0; g < G; g++) {
+                        // team walks are for generations of few rays (every lane-step of theirs costs a full wave
+                        // instruction): a generation the packet trial counted above a million rays is not timed
+                        // with them, the packet walk runs in its place
+                        const int m = (mode == 5 && sample_rays[g] > (1u << 20)) ? 3 : mode;
+                        team_timed[g] = m == 5;
                         hipEventRecord(ev[4 * g + 0], st);
-                        rtk_extend(st, mode, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false, c->launch_cache);
+                        rtk_extend(st, m, S, c->P, c->d_counters, c->cam, d_pick, 0, g, bound, c->max_blocks, false, c->launch_cache);
                         hipEventRecord(ev[4 * g + 1], st);
-                        rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks, mode);
+                        rtk_compact(st, c->P, c->d_counters, g, bound, c->max_blocks, m);
                         hipEventRecord(ev[4 * g + 2], st);
-                        rtk_shadow(st, mode, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false, c->launch_cache);
+                        rtk_shadow(st, m, S, c->P, c->d_counters, g, bound * (uint64_t)std::max(1, S.nl), c->max_blocks, false, c->launch_cache);
                         hipEventRecord(ev[4 * g + 3], st);
                         rtk_shade(st, S, c->P, c->d_counters, g, bound, c->max_blocks);
                         CAL_TRY(hipGetLastError());        // a rejected launch of this generation, named by the expression
@@ -818,6 +829,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
                         sample_rays[g] = hc.gen_count[g];
                         hipEventElapsedTime(&a, ev[4 * g + 0], ev[4 * g + 1]);
                         hipEventElapsedTime(&b, ev[4 * g + 2], ev[4 * g + 3]);
+                        if (mode == 5 && !team_timed[g]) continue;
                         te[t][mode][g] = std::min(te[t][mode][g], a);
                         tsh[t][mode][g] = std::min(tsh[t][mode][g], b);
                     }

@@ -621,28 +621,32 @@ __device__ __forceinline__ void trace(const DScene& S, float4* lds, bool active,
     else lbvh_trace_packet<ANY>(S, active, o, d, dmax, best, best_d2, uv, ts);
 }
 
-// ---------------------------------------------------------------- team walk (a ray per TEAM of lanes)
+// ---------------------------------------------------------------- team walk (the lanes of a wave share out its rays)
 // A launch with few rays ends when its LONGEST walk does: a ray that grazes through a hedge visits hundreds
-// of nodes, one dependent fetch after the other, while the chip stands all but empty.  Here T lanes walk ONE ray
-// on the 4-wide tree: every round the team takes up to T / 4 node references off its stack (in LDS) and each
-// lane tests one child box; a child that is hit and is a leaf gets its exact test at once, in the same lane, one
-// that is an inner node goes on the stack -- entries in the order a depth-first walk would visit them (children
-// of the entry that was on top end up on top, nearest last).  A walk of N steps becomes about depth + N / (T / 4)
-// rounds.  The team looks at boxes a depth-first walk would have culled after a nearer hit; the hit it reports
-// is the same (distance, primitive id) lexicographic minimum over the same exact tests.  A stack that would
-// outgrow its LDS slice (TEAM_STACK entries; past three quarters the team takes one entry per round, which is a
+// of nodes, one dependent fetch after the other, while the chip stands all but empty.  Here a wave holds NR rays
+// (records and traversal stacks in LDS) and its 64 lanes test 16 nodes of the 4-wide tree per round, one
+// child box per lane; the 16 node slots are shared out evenly among the rays that still have entries on their
+// stacks, so a ray gets 16 / NR nodes per round while all are alive and all 16 once it is the last one.  A
+// child that is hit and is a leaf gets its exact test at once, in the same lane; one that is an inner node goes
+// on its ray's stack -- entries in the order a depth-first walk would visit them (the children of the entry that
+// was on top end up on top, nearest last).  The lanes look at boxes a depth-first walk would have culled after a
+// nearer hit; the hit reported is the same (distance, primitive id) lexicographic minimum over the same exact
+// tests: candidates meet in a 64-bit atomic minimum of (distance bits, primitive) in the ray's record.  A stack
+// that would outgrow its LDS slice (TEAM_STACK entries; near the limit a ray takes one entry per round, which is a
 // depth-first walk) hands the ray to the private-stack walk.
-#ifndef TEAM_T
-#define TEAM_T 16           // closest-hit walks
+#ifndef TEAM_NR
+#define TEAM_NR 8           // rays per wave, closest-hit walks
 #endif
-#ifndef TEAM_TS
-#define TEAM_TS 8           // any-hit walks: many short rays, and nothing to reduce over the team
+#ifndef TEAM_NRS
+#define TEAM_NRS 8          // rays per wave, any-hit walks
 #endif
+#define TEAM_NR_MAX (TEAM_NR > TEAM_NRS ? TEAM_NR : TEAM_NRS)
 #define TEAM_STACK 96
-#define TEAM_LDS_INTS ((64 / (TEAM_T < TEAM_TS ? TEAM_T : TEAM_TS)) * TEAM_STACK)          // per wave
+#define TEAM_REC_F4 9       // float4 per ray record (6 used; 36 words apart: the records of a wave start in different banks)
+#define TEAM_LDS_F4 (TEAM_NR_MAX * (TEAM_REC_F4 + TEAM_STACK / 4))          // per wave: records, then stacks
 
 template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {            // v of the lane CTRL names (quad_perm / row rotation)
+__device__ __forceinline__ float dpp_f(float v) {            // v of the lane CTRL names (quad_perm)
     return bitsf((uint32_t)__builtin_amdgcn_update_dpp(0, (int)fbits(v), CTRL, 0xF, 0xF, false));
 }
 template <int CTRL>
@@ -650,56 +654,80 @@ __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp
 #define DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
 #define DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
 #define DPP_QUAD_XOR3 0x1B      // quad_perm [3,2,1,0]
-#define DPP_ROW_ROR(n) (0x120 + (n))
 
-template <int T>
-__device__ __forceinline__ float team_min(float m) {        // every lane of the team gets the minimum
-    m = fminf(m, dpp_f<DPP_QUAD_XOR1>(m));
-    m = fminf(m, dpp_f<DPP_QUAD_XOR2>(m));
-    m = fminf(m, dpp_f<DPP_ROW_ROR(4)>(m));                  // rotations inside the 16-lane row
-    m = fminf(m, dpp_f<DPP_ROW_ROR(8)>(m));
-    if (T >= 32) m = fminf(m, __shfl_xor(m, 16));
-    if (T >= 64) m = fminf(m, __shfl_xor(m, 32));
-    return m;
-}
-
-// All 64 lanes call; the lanes of a team pass the same ray.  Every lane of the team returns the result.
-template <bool ANY, int T>
-__device__ __forceinline__ void team_walk(const DScene& S, int* wave_stack, bool active, F3 o, F3 d, float dmax, int& best,
+// Record of ray r in LDS, float4 rec[r * TEAM_REC_F4 + ...]:
+//   0: o.xyz, dmax      1: d.xyz, 1/dot(d,d)      2: 1/d.xyz, dd low word      3: -(o/d).xyz, dd high word
+//   4: best primitive, best distance (bits; the two words are ONE 64-bit key, ~0 = no hit yet), u, v of that hit
+//   5: stack depth, any-hit found, redo with the private-stack walk, -
+// All 64 lanes call; lanes r < NR pass ray r of the wave (active = there is one) and get its result back.
+template <bool ANY, int NR>
+__device__ __forceinline__ void team_walk(const DScene& S, float4* wave_lds, bool active, F3 o, F3 d, float dmax, int& best,
                                           float& best_d2, HitUV& uv, TraceStats& ts) {
-    static_assert(T == 16 || T == 32 || T == 64 || (ANY && (T == 4 || T == 8)), "a team is one, two or four 16-lane rows (any-hit walks, which reduce nothing: also 4 or 8 lanes)");
-    constexpr int PMAX = T / 4;
-    const uint32_t lane = threadIdx.x & 63u, tl = lane & (uint32_t)(T - 1), team = lane / (uint32_t)T;
-    const int e = (int)(tl >> 2), c = (int)(tl & 3u);
-    int* stk = wave_stack + team * TEAM_STACK;
-    const unsigned long long team_bits = (T == 64) ? ~0ull : ((1ull << (T & 63)) - 1ull);
-    const int team_shift = (int)(team * (uint32_t)T);
-    const double dd = (double)dot3(d, d);
-    const SlabRay R = slab_ray(o, d);
-    float tmax = slab_tmax(R, dmax);
-    int sp = active ? 1 : 0;
-    if (active && tl == 0) stk[0] = 0;                        // both trees keep their root at node 0
-    int cb = -1; float cd2 = dmax; HitUV cuv; cuv.a = 0; cuv.b = 0;      // this lane's best candidate
-    bool redo = false, shadowed = false;
+    static_assert(NR == 4 || NR == 8 || NR == 16, "16 node slots per round are shared by at most 16 rays");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = lane >> 2;
+    const int c = (int)(lane & 3u);
+    float4* rec = wave_lds;
+    int* stacks = (int*)(wave_lds + NR * TEAM_REC_F4);
+    const double dd0 = (double)dot3(d, d);
+    if (lane < (uint32_t)NR) {
+        const SlabRay R = slab_ray(o, d);
+        float4* r = rec + lane * TEAM_REC_F4;
+        r[0] = make_float4(o.x, o.y, o.z, dmax);
+        r[1] = make_float4(d.x, d.y, d.z, R.inv_dd);
+        r[2] = make_float4(R.inv.x, R.inv.y, R.inv.z, __int_as_float(__double2loint(dd0)));
+        r[3] = make_float4(R.noi.x, R.noi.y, R.noi.z, __int_as_float(__double2hiint(dd0)));
+        r[4] = make_float4(bitsf(0xFFFFFFFFu), bitsf(0xFFFFFFFFu), 0.0f, 0.0f);
+        r[5] = make_float4(__int_as_float(active ? 1 : 0), __int_as_float(0), __int_as_float(0), 0.0f);
+        stacks[lane * TEAM_STACK] = 0;                            // both trees keep their root at node 0
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    while (ballot64(sp > 0) != 0ull) {
-        const int npop = sp > TEAM_STACK - 4 * PMAX ? 1 : (sp < PMAX ? sp : PMAX);
+    uint32_t alive = (uint32_t)ballot64(lane < (uint32_t)NR && active);
+    const unsigned long long t0 = S.profile ? __builtin_readcyclecounter() : 0ull;
+    uint32_t rounds = 0;
+    while (alive != 0u) {
+        rounds++;
+        // wave-uniform part (scalar unit): how many rays are alive, how many of the 16 node slots each gets, and
+        // the list of their numbers, four bits each
+        const int n = __popc(alive);
+        const int share = 16 / n;                                   // node slots per ray this round
+        const uint32_t recip = (65536u + (uint32_t)share - 1u) / (uint32_t)share;
+        unsigned long long order = 0ull;
+        {
+            uint32_t a = alive;
+            for (int i = 0; i < n; i++) { order |= (unsigned long long)__builtin_ctz(a) << (4 * i); a &= a - 1u; }
+        }
+        const int k = (int)((slot * recip) >> 16);                  // = slot / share: this lane works for the k-th ray alive,
+        const int e = (int)slot - k * share;                        //   entry e of its share
+        const bool mine = k < n;
+        const int ray = mine ? (int)((order >> (4 * k)) & 15ull) : 0;
+        const float4* rr = rec + ray * TEAM_REC_F4;
+        int* stk = stacks + ray * TEAM_STACK;
+        const int sp = mine ? __float_as_int(rr[5].x) : 0;
+        // a popped node may push four: never more pops than the free part of the stack can take the children of
+        const int room = (TEAM_STACK - sp) / 3;
+        const int want = share < room ? share : (room < 1 ? 1 : room);
+        const int npop = sp < want ? sp : want;
         const bool has = e < npop;
         const int node = has ? stk[sp - 1 - e] : 0;
-        sp -= npop;
         bool hit = false;
         float tn = 0;
         int ref = LANE_DONE;
         if (has) {
+            const float4 ri = rr[2], rn = rr[3], rk = rr[4];
+            const uint32_t kd2 = fbits(rk.y);
+            // bound of the box test: the ray's own bound until it has a hit, then the distance of the best one
+            float tmax;
+            { SlabRay Rt; Rt.inv_dd = rr[1].w; tmax = slab_tmax(Rt, (ANY || kd2 == 0xFFFFFFFFu) ? rr[0].w : bitsf(kd2)); }
             v2f tx, ty, tz;
             if (S.wide_quant) {
                 const v4f* nd = (const v4f*)S.nodes4 + 4 * (size_t)node;
                 const v4f q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 const uint32_t eb = fbits(q0.w);
-                const float ax = bitsf((eb & 0xFFu) << 23) * R.inv.x, ay = bitsf(((eb >> 8) & 0xFFu) << 23) * R.inv.y,
-                            az = bitsf(((eb >> 16) & 0xFFu) << 23) * R.inv.z;
-                const float bx = __builtin_fmaf(q0.x, R.inv.x, R.noi.x), by = __builtin_fmaf(q0.y, R.inv.y, R.noi.y),
-                            bz = __builtin_fmaf(q0.z, R.inv.z, R.noi.z);
+                const float ax = bitsf((eb & 0xFFu) << 23) * ri.x, ay = bitsf(((eb >> 8) & 0xFFu) << 23) * ri.y,
+                            az = bitsf(((eb >> 16) & 0xFFu) << 23) * ri.z;
+                const float bx = __builtin_fmaf(q0.x, ri.x, rn.x), by = __builtin_fmaf(q0.y, ri.y, rn.y),
+                            bz = __builtin_fmaf(q0.z, ri.z, rn.z);
                 const int sh = 8 * c;
                 tx = (v2f){__builtin_fmaf((float)((fbits(q1.x) >> sh) & 0xFFu), ax, bx), __builtin_fmaf((float)((fbits(q1.w) >> sh) & 0xFFu), ax, bx)};
                 ty = (v2f){__builtin_fmaf((float)((fbits(q1.y) >> sh) & 0xFFu), ay, by), __builtin_fmaf((float)((fbits(q2.x) >> sh) & 0xFFu), ay, by)};
@@ -711,9 +739,9 @@ __device__ __forceinline__ void team_walk(const DScene& S, int* wave_stack, bool
                 const float2* bx = (const float2*)(nf + 6 * c);
                 const float2 x = bx[0], y = bx[1], z = bx[2];
                 ref = __float_as_int(nf[24 + c]);
-                tx = (v2f){__builtin_fmaf(x.x, R.inv.x, R.noi.x), __builtin_fmaf(x.y, R.inv.x, R.noi.x)};
-                ty = (v2f){__builtin_fmaf(y.x, R.inv.y, R.noi.y), __builtin_fmaf(y.y, R.inv.y, R.noi.y)};
-                tz = (v2f){__builtin_fmaf(z.x, R.inv.z, R.noi.z), __builtin_fmaf(z.y, R.inv.z, R.noi.z)};
+                tx = (v2f){__builtin_fmaf(x.x, ri.x, rn.x), __builtin_fmaf(x.y, ri.x, rn.x)};
+                ty = (v2f){__builtin_fmaf(y.x, ri.y, rn.y), __builtin_fmaf(y.y, ri.y, rn.y)};
+                tz = (v2f){__builtin_fmaf(z.x, ri.z, rn.z), __builtin_fmaf(z.y, ri.z, rn.z)};
                 if (c == 0) ts.nodes += 2;
             }
             if (c == 0) ts.lane_nodes += 2;
@@ -721,87 +749,91 @@ __device__ __forceinline__ void team_walk(const DScene& S, int* wave_stack, bool
         }
         // children that are leaves: the exact test now, in the lane that holds the child
         const bool at_leaf = hit && ref < 0;
-        unsigned long long done_any = 0ull;
-#ifdef TEAM_DEBUG
-        if (has && blockIdx.x == 0 && threadIdx.x < 16) printf("ANY %d lane %d sp(after pop) %d npop %d node %d c %d ref %d hit %d tn %g tmax %g\n", (int)ANY, (int)lane, sp, npop, node, c, ref, (int)hit, tn, tmax);
-#endif
+        unsigned long long key = ~0ull;
+        float ca = 0, cb = 0;
+        bool found = false;
         if (ballot64(at_leaf) != 0ull) {
             if (at_leaf) {
                 const float4* lf = S.leaf + 3 * (size_t)(~ref);
                 const float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
+                const float4 ro = rr[0], rd = rr[1];
+                const double dd = __hiloint2double(__float_as_int(rr[3].w), __float_as_int(rr[2].w));
                 const int prim = (int)fbits(l2.y);
                 if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
                 ts.lane_prims++;
                 float d2 = 0;
                 HitUV cand;
-#ifdef TEAM_DEBUG
-                bool lt = leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand);
-                if (blockIdx.x == 0 && threadIdx.x < 16) printf("  leaf lane %d prim %d -> %d d2 %g dmax %g\n", (int)lane, prim, (int)lt, d2, dmax);
-#endif
-                if (leaf_test(o, d, dd, l0, l1, l2, dmax, d2, cand)) {
-                    if (ANY) shadowed = true;
-                    else if (cb < 0 || d2 < cd2 || (d2 == cd2 && prim < cb)) { cb = prim; cd2 = d2; cuv = cand; }
+                if (leaf_test(f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), dd, l0, l1, l2, ro.w, d2, cand)) {
+                    found = true;
+                    key = ((unsigned long long)fbits(d2) << 32) | (uint32_t)prim;
+                    ca = cand.a; cb = cand.b;
                 }
             }
-            if (ANY) done_any = ballot64(shadowed);
-            else tmax = slab_tmax(R, team_min<T>(cd2));
         }
-        const bool team_done = ANY && ((done_any >> team_shift) & team_bits) != 0ull;
-        // children that are inner nodes go on the stack
-        const bool push = hit && ref >= 0 && !team_done;
+        const unsigned long long fm = ballot64(found);
+        if (!ANY && fm != 0ull) {
+            // candidates meet in the ray's record: smallest (distance, primitive) wins, and the winner leaves its u, v
+            if (found) atomicMin((unsigned long long*)(rec + ray * TEAM_REC_F4 + 4), key);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (found && *(volatile unsigned long long*)(rec + ray * TEAM_REC_F4 + 4) == key) {
+                float* w = (float*)(rec + ray * TEAM_REC_F4 + 4);
+                w[2] = ca; w[3] = cb;
+            }
+        }
+        // children that are inner nodes go on their ray's stack
+        const bool push = hit && ref >= 0;
         const unsigned long long pm = ballot64(push);
-        if (team_done) sp = 0;
-        if (pm != 0ull) {
-            const unsigned long long tb = (pm >> team_shift) & team_bits;       // this team's pushing lanes
+        const int width = 4 * share;                                      // lanes of this ray: [width * k, + width)
+        const unsigned long long wmask = width == 64 ? ~0ull : ((1ull << (width & 63)) - 1ull);
+        const int base = (width * k) & 63;
+        {
+            const unsigned long long tb = (pm >> base) & wmask;
             const uint32_t quad = (uint32_t)(tb >> (4 * e)) & 0xFu;
-            const int above = __popcll((tb >> (4 * e)) >> 4);                    // pushed by entries deeper in the stack: they go first
+            const int above = __popcll((tb >> (4 * e)) >> 4);                  // pushed by entries deeper in the stack: they go first
             const float t1 = dpp_f<DPP_QUAD_XOR1>(tn), t2 = dpp_f<DPP_QUAD_XOR2>(tn), t3 = dpp_f<DPP_QUAD_XOR3>(tn);
             const int c1 = c ^ 1, c2 = c ^ 2, c3 = c ^ 3;
-            int farther = 0;                                                     // of my own node's children: farther ones first
+            int farther = 0;                                                   // of my own node's children: farther ones first
             farther += ((quad >> c1) & 1u) && (t1 > tn || (t1 == tn && c1 > c));
             farther += ((quad >> c2) & 1u) && (t2 > tn || (t2 == tn && c2 > c));
             farther += ((quad >> c3) & 1u) && (t3 > tn || (t3 == tn && c3 > c));
-            const int pos = sp + above + farther;
+            const int pos = sp - npop + above + farther;
             bool over = false;
             if (push) {
                 if (pos < TEAM_STACK) stk[pos] = ref;
                 else over = true;
             }
-            sp += __popcll(tb);
             const unsigned long long ov = ballot64(over);
-            if (((ov >> team_shift) & team_bits) != 0ull) { sp = 0; redo = true; }
+            const bool ray_over = ((ov >> base) & wmask) != 0ull;
+            const bool ray_found = ANY && ((fm >> base) & wmask) != 0ull;      // shadowed: nothing more to find out
+            int nsp = sp - npop + __popcll(tb);
+            if (ray_over || ray_found) nsp = 0;
+            const bool first = mine && e == 0 && c == 0;                       // the ray's first lane keeps its books
+            if (first) {
+                int* book = (int*)(rec + ray * TEAM_REC_F4 + 5);
+                book[0] = nsp;
+                if (ray_found) book[1] = 1;
+                if (ray_over) book[2] = 1;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        alive = (uint32_t)ballot64(lane < (uint32_t)NR && __float_as_int(rec[(lane < (uint32_t)NR ? lane : 0u) * TEAM_REC_F4 + 5].x) > 0);
     }
-    if (ANY) {
-#ifdef TEAM_DEBUG
-        if (blockIdx.x == 0 && threadIdx.x < 4) printf("end lane %d shadowed %d ballot %llx shift %d bits %llx\n", (int)lane, (int)shadowed, ballot64(shadowed), team_shift, team_bits);
-#endif
-        const unsigned long long sm = ballot64(shadowed);         // (by every lane: not behind a short-circuit)
-        best = ((sm >> team_shift) & team_bits) != 0ull ? 0 : -1;
-        best_d2 = 0;
-        uv.a = 0; uv.b = 0;
-    } else {
-        // lexicographic minimum of the lanes' candidates; rotations inside the 16-lane row, then across rows
-        auto take = [&](int ob, float od2, float oa, float obb) {
-            if (ob >= 0 && (cb < 0 || od2 < cd2 || (od2 == cd2 && ob < cb))) { cb = ob; cd2 = od2; cuv.a = oa; cuv.b = obb; }
-        };
-        take(dpp_i<DPP_QUAD_XOR1>(cb), dpp_f<DPP_QUAD_XOR1>(cd2), dpp_f<DPP_QUAD_XOR1>(cuv.a), dpp_f<DPP_QUAD_XOR1>(cuv.b));
-        take(dpp_i<DPP_QUAD_XOR2>(cb), dpp_f<DPP_QUAD_XOR2>(cd2), dpp_f<DPP_QUAD_XOR2>(cuv.a), dpp_f<DPP_QUAD_XOR2>(cuv.b));
-        take(dpp_i<DPP_ROW_ROR(4)>(cb), dpp_f<DPP_ROW_ROR(4)>(cd2), dpp_f<DPP_ROW_ROR(4)>(cuv.a), dpp_f<DPP_ROW_ROR(4)>(cuv.b));
-        take(dpp_i<DPP_ROW_ROR(8)>(cb), dpp_f<DPP_ROW_ROR(8)>(cd2), dpp_f<DPP_ROW_ROR(8)>(cuv.a), dpp_f<DPP_ROW_ROR(8)>(cuv.b));
-        if (T >= 32) take(__shfl_xor(cb, 16), __shfl_xor(cd2, 16), __shfl_xor(cuv.a, 16), __shfl_xor(cuv.b, 16));
-        if (T >= 64) take(__shfl_xor(cb, 32), __shfl_xor(cd2, 32), __shfl_xor(cuv.a, 32), __shfl_xor(cuv.b, 32));
-        best = cb; best_d2 = cd2; uv = cuv;
+    if (S.profile && lane == 0) { ts.walk_cycles += __builtin_readcyclecounter() - t0; ts.steps += rounds; ts.walks++; }
+    best = -1; best_d2 = dmax; uv.a = 0; uv.b = 0;
+    bool redo = false;
+    if (lane < (uint32_t)NR && active) {
+        const float4 rk = rec[lane * TEAM_REC_F4 + 4], bk = rec[lane * TEAM_REC_F4 + 5];
+        redo = __float_as_int(bk.z) != 0;
+        if (ANY) { if (__float_as_int(bk.y) != 0) { best = 0; best_d2 = 0; } }
+        else if (fbits(rk.y) != 0xFFFFFFFFu || fbits(rk.x) != 0xFFFFFFFFu) { best = (int)fbits(rk.x); best_d2 = rk.y; uv.a = rk.z; uv.b = rk.w; }
     }
     if (ballot64(redo) != 0ull) {
-        // the stack outgrew its slice (rare): this ray again, one lane, stack in private memory
+        // a stack outgrew its slice (rare): that ray again, stack in private memory
         int b; float bd; HitUV buv;
-        lbvh_trace<ANY, true>(S, redo && tl == 0, o, d, dmax, b, bd, buv, ts);
-        const int src = (int)(lane - tl);
-        const int rb = __shfl(b, src); const float rd2 = __shfl(bd, src), ra = __shfl(buv.a, src), rbb = __shfl(buv.b, src);
-        if (redo) { best = rb; best_d2 = rd2; uv.a = ra; uv.b = rbb; }
+        lbvh_trace<ANY, true>(S, redo, o, d, dmax, b, bd, buv, ts);
+        if (redo) { best = b; best_d2 = bd; uv = buv; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                     // the next call rewrites the records
 }
 
 // Work counters of a traversal launch.  Every wave adds its totals to a slot of its own
@@ -1024,22 +1056,24 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
     }
 }
 
-// extend_one for a launch whose walks are team walks: the wave owns the 64 / T consecutive rays of `item`, one
-// per team; lane 0 of each team writes the ray's record.  The three ballot masks of a 64-ray group cannot be put
-// together by one wave here (a group is spread over T waves): each ray leaves a flag byte (P.rflag: 1 hit,
-// 2 spawns a reflection ray, 4 a refraction ray) and the scan kernel builds the masks from the bytes.
-template <int T>
+// extend_one for a launch whose walks are team walks: the wave owns the NR consecutive rays of `item`, lane r
+// the r-th of them.  The three ballot masks of a 64-ray group cannot be put together by one wave here (a group
+// is spread over 64 / NR waves): each ray leaves a flag byte (P.rflag: 1 hit, 2 spawns a reflection ray,
+// 4 a refraction ray) and the scan kernel builds the masks from the bytes.
+template <int NR>
 __device__ __forceinline__ void extend_team(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
-                                            uint32_t count, uint64_t item, int* wave_stack, TraceStats& ts) {
-    const uint32_t lane = threadIdx.x & 63u, tl = lane & (uint32_t)(T - 1), team = lane / (uint32_t)T;
-    const uint64_t i64 = item * (uint64_t)(64 / T) + team;
-    const bool inrange = i64 < (uint64_t)count;
+                                            uint32_t count, uint64_t item, float4* wave_lds, TraceStats& ts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t i64 = item * (uint64_t)NR + lane;
+    const bool inrange = lane < (uint32_t)NR && i64 < (uint64_t)count;
     const uint32_t i = inrange ? (uint32_t)i64 : 0u;
-    RayRec R = load_ray(P, G, g, i, start + i);
+    RayRec R;
+    R.o = f3(0, 0, 0); R.d = f3(0, 0, 1); R.parent = 0; R.slot = 0; R.valid = false;
+    if (inrange) R = load_ray(P, G, g, i, start + i);
     const bool active = inrange && R.valid;
     int best; float best_d2; HitUV uv;
-    team_walk<false, T>(S, wave_stack, active, R.o, R.d, __builtin_inff(), best, best_d2, uv, ts);
-    if (tl != 0 || !inrange) return;
+    team_walk<false, NR>(S, wave_lds, active, R.o, R.d, __builtin_inff(), best, best_d2, uv, ts);
+    if (!inrange) return;
     uint32_t bits = 0;
     if (active && best >= 0) {
         F3 point, normal; int mat;
@@ -1187,7 +1221,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
 
 template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPool P, DCounters* C, GenSrc G, int g) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : ACCEL == 5 ? TEAM_LDS_INTS * (RT_BLOCK / 64) / 4 : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : ACCEL == 5 ? TEAM_LDS_F4 * (RT_BLOCK / 64) : 1];
     if (C->overflow) return;   // ray slots past an overflow were never written: the host re-runs the batch
     const uint32_t start = gen_start(C, g);
     const uint32_t count = gen_size(C, g, start, P.capacity);
@@ -1215,9 +1249,8 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
             });
         }
     } else if (ACCEL == 5) {
-        constexpr uint64_t per_wave = 64 / TEAM_T;
-        for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + per_wave - 1) / per_wave, [&](uint64_t item) {
-            extend_team<TEAM_T>(S, P, G, g, start, count, item, (int*)lds + (threadIdx.x >> 6) * TEAM_LDS_INTS, ts);
+        for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + TEAM_NR - 1) / TEAM_NR, [&](uint64_t item) {
+            extend_team<TEAM_NR>(S, P, G, g, start, count, item, lds + (threadIdx.x >> 6) * TEAM_LDS_F4, ts);
         });
     } else {
         for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + 63) >> 6, [&](uint64_t grp) {
@@ -1520,7 +1553,7 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, in
 // around their common origin.)
 template <int ACCEL, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPool P, DCounters* C, int g) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : ACCEL == 5 ? TEAM_LDS_INTS * (RT_BLOCK / 64) / 4 : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : (ACCEL == 2 || ACCEL == 4) ? LANE_STACK_F4 : ACCEL == 5 ? TEAM_LDS_F4 * (RT_BLOCK / 64) : 1];
     if (C->overflow) return;
     const uint32_t nh = C->hit_count[g];
     const uint64_t items = (uint64_t)nh * (uint64_t)S.nl;
@@ -1556,20 +1589,21 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
             });
         }
     } else if (ACCEL == 5) {
-        // team walks: the wave owns 64 / T consecutive items, one per team
-        constexpr uint64_t per_wave = 64 / TEAM_TS;
+        // team walks: the wave owns TEAM_NRS consecutive items, lane r the r-th
         const uint32_t lane = threadIdx.x & 63u;
-        for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + per_wave - 1) / per_wave, [&](uint64_t pk) {
-            const uint64_t k = pk * per_wave + lane / TEAM_TS;
-            const bool active = k < items;
-            const uint32_t h = active ? (uint32_t)(k / (uint32_t)S.nl) : 0;
-            const int j = active ? (int)(k - (uint64_t)h * (uint32_t)S.nl) : 0;
-            const F3 point = f3(P.hp[P.hitlist[h]]);
-            F3 I; float dist2;
-            light_dir(S.lights[j], point, I, dist2);
+        for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + TEAM_NRS - 1) / TEAM_NRS, [&](uint64_t pk) {
+            const uint64_t k = pk * TEAM_NRS + lane;
+            const bool active = lane < TEAM_NRS && k < items;
+            F3 point = f3(0, 0, 0), I = f3(0, 0, 1); float dist2 = 0;
+            if (active) {
+                const uint32_t h = (uint32_t)(k / (uint32_t)S.nl);
+                const int j = (int)(k - (uint64_t)h * (uint32_t)S.nl);
+                point = f3(P.hp[P.hitlist[h]]);
+                light_dir(S.lights[j], point, I, dist2);
+            }
             int best; float best_d2; HitUV uv;
-            team_walk<true, TEAM_TS>(S, (int*)lds + (threadIdx.x >> 6) * TEAM_LDS_INTS, active, point, I, dist2, best, best_d2, uv, ts);
-            if (active && (lane & (TEAM_TS - 1)) == 0) P.occl[k] = (best >= 0) ? 1 : 0;
+            team_walk<true, TEAM_NRS>(S, lds + (threadIdx.x >> 6) * TEAM_LDS_F4, active, point, I, dist2, best, best_d2, uv, ts);
+            if (active) P.occl[k] = (best >= 0) ? 1 : 0;
         });
     } else {
         for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + 63) >> 6,
@@ -1835,26 +1869,23 @@ __global__ void k_rowbase(int world, int ntx, int nty, uint32_t* rowbase) {
 template <int ACCEL, bool ANY>
 __global__ __launch_bounds__(RT_BLOCK) void k_query(DScene S, int64_t n, const float* o, const float* d,
                                                     const float* dmax, int* prim_out, float* d2_out) {
-    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : ACCEL == 5 ? TEAM_LDS_INTS * (RT_BLOCK / 64) / 4 : 1];
+    __shared__ float4 lds[ACCEL == 1 ? BRUTE_CHUNK : ACCEL == 5 ? TEAM_LDS_F4 * (RT_BLOCK / 64) : 1];
     TraceStats ts;
     if (ACCEL == 5) {
-        // team walks: a wave takes its 64 rays 64 / T at a time, one per team
-        constexpr int per = 64 / TEAM_T;
-        const int lane = (int)(threadIdx.x & 63u), team = lane / TEAM_T;
+        // team walks: a wave takes its 64 rays NR at a time, lane r the r-th
+        constexpr int NR = ANY ? TEAM_NRS : TEAM_NR;
+        const int lane = (int)(threadIdx.x & 63u);
         for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 64 * 64; base < n; base += (int64_t)gridDim.x * blockDim.x) {
-            for (int pass = 0; pass < TEAM_T; pass++) {
-                const int64_t i = base + (int64_t)pass * per + team;
-                const bool active = i < n;
+            for (int pass = 0; pass < 64 / NR; pass++) {
+                const int64_t i = base + (int64_t)pass * NR + lane;
+                const bool active = lane < NR && i < n;
                 const int64_t ii = active ? i : 0;
                 F3 ro = f3(o[3 * ii], o[3 * ii + 1], o[3 * ii + 2]);
                 F3 rd = f3(d[3 * ii], d[3 * ii + 1], d[3 * ii + 2]);
                 float dm = dmax ? dmax[ii] : __builtin_inff();
                 int best; float best_d2; HitUV uv;
-                team_walk<ANY, TEAM_T>(S, (int*)lds + (threadIdx.x >> 6) * TEAM_LDS_INTS, active, ro, rd, dm, best, best_d2, uv, ts);
-#ifdef TEAM_DEBUG
-                if (blockIdx.x == 0 && threadIdx.x < 4) printf("query lane %d pass %d best %d active %d\n", lane, pass, best, (int)active);
-#endif
-                if (active && (lane & (TEAM_T - 1)) == 0) {
+                team_walk<ANY, NR>(S, lds + (threadIdx.x >> 6) * TEAM_LDS_F4, active, ro, rd, dm, best, best_d2, uv, ts);
+                if (active) {
                     prim_out[i] = best;
                     if (d2_out) d2_out[i] = best >= 0 ? best_d2 : __builtin_inff();
                 }
@@ -1913,7 +1944,7 @@ static void launch_extend(hipStream_t st, int accel, const DScene& S, const DPoo
                                  : accel == 4 ? resident_blocks(k_extend<4, COUNT>, max_blocks)
                                  : accel == 5 ? resident_blocks(k_extend<5, COUNT>, max_blocks)
                                               : resident_blocks(k_extend<3, COUNT>, max_blocks);
-    dim3 grid(grid_for(accel == 5 ? bound * TEAM_T : bound, res[accel])), block(RT_BLOCK);
+    dim3 grid(grid_for(accel == 5 ? bound * (64 / TEAM_NR) : bound, res[accel])), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL((k_extend<1, COUNT>), grid, block, 0, st, S, P, C, G, g);
     else if (accel == 2) hipLaunchKernelGGL((k_extend<2, COUNT>), grid, block, 0, st, S, P, C, G, g);
     else if (accel == 4) hipLaunchKernelGGL((k_extend<4, COUNT>), grid, block, 0, st, S, P, C, G, g);
@@ -1941,7 +1972,7 @@ static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPoo
                                  : accel == 4 ? resident_blocks(k_shadow<4, COUNT>, max_blocks)
                                  : accel == 5 ? resident_blocks(k_shadow<5, COUNT>, max_blocks)
                                               : resident_blocks(k_shadow<3, COUNT>, max_blocks);
-    dim3 grid(grid_for(accel == 5 ? bound * TEAM_TS : bound, res[accel])), block(RT_BLOCK);
+    dim3 grid(grid_for(accel == 5 ? bound * (64 / TEAM_NRS) : bound, res[accel])), block(RT_BLOCK);
     if (accel == 1) hipLaunchKernelGGL((k_shadow<1, COUNT>), grid, block, 0, st, S, P, C, g);
     else if (accel == 2) hipLaunchKernelGGL((k_shadow<2, COUNT>), grid, block, 0, st, S, P, C, g);
     else if (accel == 4) hipLaunchKernelGGL((k_shadow<4, COUNT>), grid, block, 0, st, S, P, C, g);
