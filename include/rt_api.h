@@ -228,9 +228,10 @@ int rt_query_rays(rt_ctx* ctx, int64_t n, const float* o, const float* d, const 
  * later renders count node / primitive fetches and tests into rt_stats; off by default.
  * The image does not depend on it. */
 int rt_set_work_counters(rt_ctx* ctx, int on);
-/* Measurement hook: on != 0 makes later renders fill rt_stats.ms_extend / ms_shadow / ms_shade /
- * ms_other (HIP events between the stage launches; the environment variable RT_STAGE_TIMES
- * does the same for every context). */
+/* Measurement hook: on = 1 makes later renders fill rt_stats.ms_extend / ms_shadow / ms_shade /
+ * ms_other (HIP events between the stage launches); on = 2 only ms_extend, on = 3 only ms_shadow (an
+ * event before and after every launch of that kind: a third of the events, for frames short enough to
+ * notice them).  The environment variable RT_STAGE_TIMES=1|2|3 does the same for every context. */
 int rt_set_stage_times(rt_ctx* ctx, int on);
 /* Primary ray of (x[i], y[i], sample j[i]) -- RayTrace::getRay (src/raytrace.cpp:441-485). */
 int rt_primary_rays(rt_ctx* ctx, int64_t n, const int32_t* x, const int32_t* y, const int32_t* j,

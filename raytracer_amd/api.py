@@ -406,9 +406,10 @@ class Tracer:
         if rc != RT_OK:
             raise RtError(rc, "rt_assemble_shards_noalloc")
 
-    def set_stage_times(self, on: bool):
-        """Fill RtStats.ms_extend / ms_shadow / ms_shade / ms_other from the next render on."""
-        rc = self._lib.rt_set_stage_times(self._ctx, 1 if on else 0)
+    def set_stage_times(self, on):
+        """Fill RtStats.ms_extend / ms_shadow / ms_shade / ms_other from the next render on
+        (2: only ms_extend, 3: only ms_shadow, with a third of the events)."""
+        rc = self._lib.rt_set_stage_times(self._ctx, int(on) if on in (2, 3) else (1 if on else 0))
         if rc != RT_OK:
             raise RtError(rc, "rt_set_stage_times")
 

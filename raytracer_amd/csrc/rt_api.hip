@@ -99,7 +99,7 @@ struct rt_ctx {
     bool team_walks = true;      // RT_TEAM_WALKS=0: calibration leaves the team walk out
     uint32_t tiles_cap = 0;    // batches of this scene that overflowed a pool that could not grow were split: keep to that size
     bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
-    bool stage_times = false;  // HIP events between the stage launches (rt_set_stage_times / RT_STAGE_TIMES)
+    int stage_times = 0;       // HIP events between the stage launches (rt_set_stage_times / RT_STAGE_TIMES): 1 every stage, 2 only the extend launches, 3 only the shadow launches
     rt_progress_fn progress = nullptr; void* progress_user = nullptr;
     uint64_t grown_capacity = 0;   // pool size a single-tile batch needed beyond an explicit rt_options.pool_rays
     RtkLaunchCache launch_cache{}; // resident-block counts of the traversal kernels on THIS device
@@ -182,7 +182,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     if (opt) c->opt = *opt;
     for (int g = 0; g <= RT_MAX_GEN; g++) { c->mode_extend[g] = 3; c->mode_shadow[g] = 3; }
     if (const char* e = getenv("RT_COUNT_WORK")) c->count_work = atoi(e) != 0;
-    c->stage_times = getenv("RT_STAGE_TIMES") != nullptr;
+    if (const char* e = getenv("RT_STAGE_TIMES")) c->stage_times = (atoi(e) == 2 || atoi(e) == 3) ? atoi(e) : 1;
     if (const char* e = getenv("RT_OVERLAP_RAYS")) c->overlap_rays = strtoull(e, nullptr, 10);
     if (const char* e = getenv("RT_TEAM_WALKS")) c->team_walks = atoi(e) != 0;
     if (const char* e = getenv("RT_PACKET_GENS")) {
@@ -514,6 +514,8 @@ struct StageTimes {
     std::vector<int> cat;            // category of the span that ENDS at ev[i+1]
     hipStream_t st = nullptr;
     std::vector<hipEvent_t>* pool = nullptr;   // the context's spare events: creating one costs microseconds, a frame uses dozens
+    int only = -1;                   // >= 0: only spans of this category are timed (an event before and one after each: an event costs
+                                     // the stream a few microseconds, which a frame of a few hundred notices)
     StageTimes() = default;
     StageTimes(const StageTimes&) = delete;
     StageTimes& operator=(const StageTimes&) = delete;
@@ -525,8 +527,14 @@ struct StageTimes {
         }
         ev.clear(); cat.clear();
     }
+    void begin(int category) {       // start of a span of `category` (needed only when the spans before it are not timed)
+        if (on && only >= 0 && only == category) record(-1);
+    }
     void mark(int category) {
-        if (!on) return;
+        if (!on || (only >= 0 && category != only)) return;
+        record(category);
+    }
+    void record(int category) {
         hipEvent_t e = nullptr;
         if (pool && !pool->empty()) { e = pool->back(); pool->pop_back(); }
         if ((!e && hipEventCreate(&e) != hipSuccess) || hipEventRecord(e, st) != hipSuccess) {
@@ -631,7 +639,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     }
     hipStream_t B = c->stream2;
     StageTimes tmB;
-    tmB.st = B; tmB.on = tm.on && any_ov; tmB.pool = &c->event_pool;
+    tmB.st = B; tmB.on = tm.on && any_ov; tmB.pool = &c->event_pool; tmB.only = tm.only;
     for (int g = 0; g <= S.max_depth; g++) {
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
@@ -642,6 +650,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         DPool P = c->P;
         if (any_ov && (g & 1)) { P.hp = c->hp2; P.hn = c->hn2; P.hd = c->hd2; P.hitlist = c->hitlist2; }
         if (ov && g - 2 >= first_ov) { hipStreamWaitEvent(st, c->ev_light[g - 2], 0); tm.mark(-1); }
+        tm.begin(0);
         rtk_extend(st, acc_e, S, P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work, c->launch_cache, ov);
         LAUNCH_CHECK("extend", g);
         tm.mark(0);
@@ -650,6 +659,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         tm.mark(3);
         const uint64_t items = bound * (uint64_t)std::max(1, S.nl);
         if (!ov) {
+            tm.begin(1);
             rtk_shadow(st, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work, c->launch_cache);
             LAUNCH_CHECK("shadow", g);
             tm.mark(1);
@@ -666,6 +676,7 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
             tmB.mark(-1);
             if (g >= 1) rtk_miss(B, S, P, c->d_counters, g, bound, c->max_blocks);
             tmB.mark(3);
+            tmB.begin(1);
             rtk_shadow(B, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work, c->launch_cache);
             tmB.mark(1);
             rtk_shade(B, S, P, c->d_counters, g, bound, c->max_blocks, 2);
@@ -944,7 +955,8 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
     StageTimes tm;
     tm.st = c->stream;
     tm.pool = &c->event_pool;
-    tm.on = stats != nullptr && c->stage_times;
+    tm.on = stats != nullptr && c->stage_times != 0;
+    tm.only = c->stage_times == 2 ? 0 : (c->stage_times == 3 ? 1 : -1);
     rt_stats acc{};
     double stage_b[4] = {0, 0, 0, 0};
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -1273,7 +1285,7 @@ extern "C" int rt_set_progress_callback(rt_ctx* c, rt_progress_fn fn, void* user
 
 extern "C" int rt_set_stage_times(rt_ctx* c, int on) {
     if (!c) return RT_ERR_INVALID;
-    c->stage_times = on != 0;
+    c->stage_times = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
     return RT_OK;
 }
 

@@ -376,10 +376,11 @@ __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const S
             float kk[4]; bool hh[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const float tlx = __builtin_fmaf((float)((lx >> (8 * c)) & 0xFFu), ax, bx), thx = __builtin_fmaf((float)((hx >> (8 * c)) & 0xFFu), ax, bx);
-                const float tly = __builtin_fmaf((float)((ly >> (8 * c)) & 0xFFu), ay, by), thy = __builtin_fmaf((float)((hy >> (8 * c)) & 0xFFu), ay, by);
-                const float tlz = __builtin_fmaf((float)((lz >> (8 * c)) & 0xFFu), az, bz), thz = __builtin_fmaf((float)((hz >> (8 * c)) & 0xFFu), az, bz);
-                hh[c] = slab_hit<8>((v2f){tlx, thx}, (v2f){tly, thy}, (v2f){tlz, thz}, tmax, kk[c]);
+                // (lo, hi) plane of an axis in one packed multiply-add
+                const v2f tx = __builtin_elementwise_fma((v2f){(float)((lx >> (8 * c)) & 0xFFu), (float)((hx >> (8 * c)) & 0xFFu)}, (v2f){ax, ax}, (v2f){bx, bx});
+                const v2f ty = __builtin_elementwise_fma((v2f){(float)((ly >> (8 * c)) & 0xFFu), (float)((hy >> (8 * c)) & 0xFFu)}, (v2f){ay, ay}, (v2f){by, by});
+                const v2f tz = __builtin_elementwise_fma((v2f){(float)((lz >> (8 * c)) & 0xFFu), (float)((hz >> (8 * c)) & 0xFFu)}, (v2f){az, az}, (v2f){bz, bz});
+                hh[c] = slab_hit<8>(tx, ty, tz, tmax, kk[c]);
             }
             k0 = kk[0]; k1 = kk[1]; k2 = kk[2]; k3 = kk[3];
             h0 = hh[0]; h1 = hh[1]; h2 = hh[2]; h3 = hh[3];
@@ -1612,6 +1613,48 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
     if (COUNT) flush_stats(P, C, 1, ts);
 }
 
+// One unoccluded light's share of getColor (src/raytrace.cpp:541-587): diffuse and specular terms added to
+// (rval, gval, bval) in the reference's order and precision.
+__device__ __forceinline__ void add_light(const DLight& L, F3 point, F3 normal, F3 direct, F3 dif, F3 spec, float ns,
+                                          float& rval, float& gval, float& bval) {
+    F3 I; float dist2f;
+    light_dir(L, point, I, dist2f);
+    double dist = (double)dist2f;
+    double dotni = (double)dot3(normal, I);
+    double cosAlpha = (dotni > 0) ? dotni : 0;
+    F3 lc = f3(L.cr, L.cg, L.cb);
+    F3 illum = lc;
+    if (L.type == 2) {
+        illum = illum * (float)(1.0 / dist);
+    } else if (L.type == 3) {
+        double alpha = acos(cosAlpha);
+        if (alpha < (double)L.a1) illum = lc * (float)(1.0 / dist);
+        else if (alpha > (double)L.a2) illum = f3(0, 0, 0);
+        else {
+            double amt = 1 - ((alpha - (double)L.a1) / (double)(L.a2 - L.a1));
+            illum = lc * (float)((1.0 / dist) * amt);
+        }
+    }
+    rval = (float)((double)rval + (double)(dif.x * illum.x) * cosAlpha);
+    gval = (float)((double)gval + (double)(dif.y * illum.y) * cosAlpha);
+    bval = (float)((double)bval + (double)(dif.z * illum.z) * cosAlpha);
+    F3 ref = (normal * (float)(2.0 * dotni)) - I;
+    F3 Vv = direct * -1.0f;
+    double powval = (double)dot3(norm3(Vv), norm3(ref));
+    double pspec = (powval < 0.0) ? 0.0 : pow(powval, (double)ns);
+    rval = (float)((double)rval + ((double)spec.x * pspec) * (double)illum.x);
+    gval = (float)((double)gval + ((double)spec.y * pspec) * (double)illum.y);
+    bval = (float)((double)bval + ((double)spec.z * pspec) * (double)illum.z);
+}
+// Directions of the secondary rays of a hit (src/raytrace.cpp:589-593, :600-624); irdir = -direction of the ray that hit.
+__device__ __forceinline__ F3 reflect_dir(F3 normal, F3 irdir) { return (normal * (2.0f * dot3(normal, irdir))) - irdir; }
+__device__ __forceinline__ F3 refract_dir(const Spawn& sp, F3 normal, F3 irdir) {
+    F3 refdir;
+    if (sp.dni >= 0) refdir = (normal * (float)(sp.ior * sp.dni - __builtin_sqrt(sp.tir))) - (irdir * (float)sp.ior);
+    else             refdir = (normal * (float)(sp.ior * sp.dni + __builtin_sqrt(sp.tir))) - (irdir * (float)sp.ior);
+    return norm3(refdir);
+}
+
 // ---------------------------------------------------------------- shade + spawn
 // getColor (src/raytrace.cpp:488-632) without the recursion: local illumination
 // with the shadow results, then the reflection / refraction rays of the next
@@ -1655,34 +1698,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PHASE 
         for (int j = 0; j < (phase == 1 ? 0 : S.nl); j++) {
             const DLight L = S.lights[j];
             if (P.occl[(uint64_t)h * (uint32_t)S.nl + j]) continue;
-            F3 I; float dist2f;
-            light_dir(L, point, I, dist2f);
-            double dist = (double)dist2f;
-            double dotni = (double)dot3(normal, I);
-            double cosAlpha = (dotni > 0) ? dotni : 0;
-            F3 lc = f3(L.cr, L.cg, L.cb);
-            F3 illum = lc;
-            if (L.type == 2) {
-                illum = illum * (float)(1.0 / dist);
-            } else if (L.type == 3) {
-                double alpha = acos(cosAlpha);
-                if (alpha < (double)L.a1) illum = lc * (float)(1.0 / dist);
-                else if (alpha > (double)L.a2) illum = f3(0, 0, 0);
-                else {
-                    double amt = 1 - ((alpha - (double)L.a1) / (double)(L.a2 - L.a1));
-                    illum = lc * (float)((1.0 / dist) * amt);
-                }
-            }
-            rval = (float)((double)rval + (double)(dif.x * illum.x) * cosAlpha);
-            gval = (float)((double)gval + (double)(dif.y * illum.y) * cosAlpha);
-            bval = (float)((double)bval + (double)(dif.z * illum.z) * cosAlpha);
-            F3 ref = (normal * (float)(2.0 * dotni)) - I;
-            F3 Vv = direct * -1.0f;
-            double powval = (double)dot3(norm3(Vv), norm3(ref));
-            double pspec = (powval < 0.0) ? 0.0 : pow(powval, (double)ns);
-            rval = (float)((double)rval + ((double)spec.x * pspec) * (double)illum.x);
-            gval = (float)((double)gval + ((double)spec.y * pspec) * (double)illum.y);
-            bval = (float)((double)bval + ((double)spec.z * pspec) * (double)illum.z);
+            add_light(L, point, normal, direct, dif, spec, ns, rval, gval, bval);
         }
         F3 irdir = direct * -1.0f;
         Spawn sp = spawn_of(spec, trans, iorf, direct, normal);
@@ -1705,17 +1721,14 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PHASE 
         uint64_t at = (uint64_t)next_start + cbase + (uint32_t)__popcll(mrefl & below) + (uint32_t)__popcll(mrefr & below);
         if (at + (sp.refl ? 1u : 0u) + (sp.refr ? 1u : 0u) > (uint64_t)P.capacity) continue;   // overflow, flagged by the scan
         if (sp.refl) {
-            F3 rfd = (normal * (2.0f * dot3(normal, irdir))) - irdir;
+            F3 rfd = reflect_dir(normal, irdir);
             P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
             P.d[at] = make_float4(rfd.x, rfd.y, rfd.z, bitsf(0u));
             P.link[at] = r;
             at++;
         }
         if (sp.refr) {
-            F3 refdir;
-            if (sp.dni >= 0) refdir = (normal * (float)(sp.ior * sp.dni - __builtin_sqrt(sp.tir))) - (irdir * (float)sp.ior);
-            else             refdir = (normal * (float)(sp.ior * sp.dni + __builtin_sqrt(sp.tir))) - (irdir * (float)sp.ior);
-            F3 rad = norm3(refdir);
+            F3 rad = refract_dir(sp, normal, irdir);
             P.o[at] = make_float4(point.x, point.y, point.z, bitsf(r));
             P.d[at] = make_float4(rad.x, rad.y, rad.z, bitsf(1u));
             P.link[at] = r | 0x80000000u;
