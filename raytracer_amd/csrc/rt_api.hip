@@ -96,6 +96,8 @@ struct rt_ctx {
     // incoherent ones the per-lane walk); RT_PACKET_GENS / RT_PACKET_SHADOW_GENS force it.
     int8_t mode_extend[RT_MAX_GEN + 1], mode_shadow[RT_MAX_GEN + 1];
     bool tuned = false, forced_modes = false;
+    bool shade_shadowed = false; // the last batch ran without shadow launches
+    bool inline_shadows = false; // brute-force scene whose primitives fit the shade kernel's LDS (RT_INLINE_SHADOWS=0 turns it off)
     bool team_walks = true;      // RT_TEAM_WALKS=0: calibration leaves the team walk out
     uint32_t tiles_cap = 0;    // batches of this scene that overflowed a pool that could not grow were split: keep to that size
     bool count_work = false;   // traversal kernels count fetches and tests (rt_set_work_counters)
@@ -410,6 +412,7 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
         accel = RT_ACCEL_BRUTE;
     }
     c->accel = accel;
+    c->inline_shadows = rtk_shade_can_shadow(S.ns, S.nt) && !(getenv("RT_INLINE_SHADOWS") && atoi(getenv("RT_INLINE_SHADOWS")) == 0);
     c->tuned = false;
     c->gen_rays_known = false;
     for (int g = 0; g <= RT_MAX_GEN; g++) c->gen_rays[g] = c->gen_rays_frame[g] = 0;
@@ -659,11 +662,17 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
         tm.mark(3);
         const uint64_t items = bound * (uint64_t)std::max(1, S.nl);
         if (!ov) {
-            tm.begin(1);
-            rtk_shadow(st, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work, c->launch_cache);
-            LAUNCH_CHECK("shadow", g);
-            tm.mark(1);
-            rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, 0);
+            // a brute-force scene small enough to sit in LDS: the shade launch answers its own shadow queries
+            // (not while the work counters are on: they count the shadow launch's tests)
+            const bool shade_shadows = c->accel == RT_ACCEL_BRUTE && c->inline_shadows && !c->count_work && !S.profile;
+            c->shade_shadowed = shade_shadows;
+            if (!shade_shadows) {
+                tm.begin(1);
+                rtk_shadow(st, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work, c->launch_cache);
+                LAUNCH_CHECK("shadow", g);
+                tm.mark(1);
+            }
+            rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, shade_shadows ? 3 : 0);
             LAUNCH_CHECK("shade", g);
             tm.mark(2);
         } else {
@@ -1022,7 +1031,7 @@ static int render_internal(rt_ctx* c, int rank, int world, int shard_mode, uint8
             acc.lane_node_tests[k] += br.lane_nodes[k]; acc.lane_prim_tests[k] += br.lane_prims[k];
         }
         acc.launches_extend += c->S.max_depth + 1;
-        acc.launches_shadow += c->S.nl ? c->S.max_depth + 1 : 0;
+        acc.launches_shadow += (c->S.nl && !c->shade_shadowed) ? c->S.max_depth + 1 : 0;
         acc.generations = std::max(acc.generations, br.generations);
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

@@ -23,7 +23,9 @@ void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C);
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks, int extend_accel);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks, bool count, RtkLaunchCache& cache);
-// phase 0: lights + hand-over + spawn; 1: spawn only; 2: lights + hand-over only (overlapped pipeline)
+// phase 0: lights + hand-over + spawn; 1: spawn only; 2: lights + hand-over only (overlapped pipeline);
+// 3: as 0 with the shadow queries answered inside (no shadow launch before it), for scenes rtk_shade_can_shadow accepts
+bool rtk_shade_can_shadow(int ns, int nt);
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks,
                int phase = 0);
 // background for the missed rays of generation g >= 1 that an extend launch with defer_miss left alone

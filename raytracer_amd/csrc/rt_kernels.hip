@@ -1655,6 +1655,25 @@ __device__ __forceinline__ F3 refract_dir(const Spawn& sp, F3 normal, F3 irdir) 
     return norm3(refdir);
 }
 
+// Any-hit query against primitives that sit in LDS for the whole launch (scenes of a handful of primitives):
+// brute_trace<true> without the staging, same order, same tests.
+#define SHADE_MAX_SPH 256
+#define SHADE_MAX_TRI 128
+__device__ __forceinline__ bool resident_any_hit(const float4* sph, int ns, const float4* tri, int nt, F3 o, F3 d, float dmax) {
+    const double dd = (double)dot3(d, d);
+    for (int i = 0; i < ns; i++) {
+        float d2, tf;
+        if (sphere_test(o, d, dd, sph[i], dmax, d2, tf)) return true;
+    }
+    for (int i = 0; i < nt; i++) {
+        F3 a, ab, ac;
+        tri_load(tri + 3 * i, a, ab, ac);
+        TriHit h;
+        if (tri_test(o, d, a, ab, ac, dmax, h)) return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------- shade + spawn
 // getColor (src/raytrace.cpp:488-632) without the recursion: local illumination
 // with the shadow results, then the reflection / refraction rays of the next
@@ -1663,9 +1682,18 @@ __device__ __forceinline__ F3 refract_dir(const Spawn& sp, F3 normal, F3 irdir) 
 // without tracing).
 // PHASE 0: the whole of getColor; 1: only the spawn (child rays; no lights, so few registers: 8 waves per
 // SIMD); 2: only the colour (lights, hand-over).  1 and 2 together do what 0 does, for the overlapped pipeline.
+// 3: as 0, and the shadow query of every light is answered here, against primitives kept in LDS: a scene of a
+// handful of primitives has no use for a shadow launch of its own and the round trip of its flags through memory.
 template <int PHASE>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ? 1 : RT_SHADE_WAVES, PHASE == 1 ? 8 : RT_SHADE_WAVES))) void k_shade(DScene S, DPool P, DCounters* C, int g) {
-    constexpr int phase = PHASE;
+    constexpr int phase = PHASE == 3 ? 0 : PHASE;
+    __shared__ float4 l_sph[PHASE == 3 ? SHADE_MAX_SPH : 1];
+    __shared__ float4 l_tri[PHASE == 3 ? 3 * SHADE_MAX_TRI : 1];
+    if (PHASE == 3) {
+        for (int i = threadIdx.x; i < S.ns; i += blockDim.x) l_sph[i] = S.sph[i];
+        for (int i = threadIdx.x; i < 3 * S.nt; i += blockDim.x) l_tri[i] = S.tri[i];
+        __syncthreads();
+    }
     if (C->overflow) return;
     const uint32_t start = gen_start(C, g);
     const uint32_t nh = C->hit_count[g];
@@ -1697,7 +1725,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PHASE 
         rval *= S.ambient.x; gval *= S.ambient.y; bval *= S.ambient.z;
         for (int j = 0; j < (phase == 1 ? 0 : S.nl); j++) {
             const DLight L = S.lights[j];
-            if (P.occl[(uint64_t)h * (uint32_t)S.nl + j]) continue;
+            if (PHASE == 3) {
+                F3 sI; float sdist2;
+                light_dir(L, point, sI, sdist2);
+                if (resident_any_hit(l_sph, S.ns, l_tri, S.nt, point, sI, sdist2)) continue;
+            } else if (P.occl[(uint64_t)h * (uint32_t)S.nl + j]) continue;
             add_light(L, point, normal, direct, dif, spec, ns, rval, gval, bval);
         }
         F3 irdir = direct * -1.0f;
@@ -1998,11 +2030,13 @@ void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
     if (count || S.profile) launch_shadow<true>(st, accel, S, P, C, g, bound, max_blocks, cache.shadow[1]);
     else launch_shadow<false>(st, accel, S, P, C, g, bound, max_blocks, cache.shadow[0]);
 }
+bool rtk_shade_can_shadow(int ns, int nt) { return ns <= SHADE_MAX_SPH && nt <= SHADE_MAX_TRI; }
 void rtk_shade(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound,
                int max_blocks, int phase) {
     dim3 grid(grid_for(bound, max_blocks)), block(RT_BLOCK);
     if (phase == 1) hipLaunchKernelGGL(k_shade<1>, grid, block, 0, st, S, P, C, g);
     else if (phase == 2) hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, S, P, C, g);
+    else if (phase == 3) hipLaunchKernelGGL(k_shade<3>, grid, block, 0, st, S, P, C, g);
     else hipLaunchKernelGGL(k_shade<0>, grid, block, 0, st, S, P, C, g);
 }
 void rtk_miss(hipStream_t st, const DScene& S, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks) {

@@ -356,6 +356,29 @@ def test_every_walk_renders_the_same_image(tracer, monkeypatch, name, kw):
         assert st.rays == st0.rays, label
 
 
+@pytest.mark.parametrize("name,kw", [("spheres1", dict(width=320, height=240, spp=1)),
+                                     ("spheres2", dict(width=200, height=150, spp=4)),
+                                     ("outdoor_spot", dict(width=240, height=135, spp=4)),
+                                     ("spot_falloff", dict(width=160, height=120, spp=2)),
+                                     ("test_reasonable", dict(width=97, height=65, spp=2)),
+                                     ("bvhtest", dict(width=120, height=90, spp=2))])
+def test_shadow_queries_inside_the_shade_launch_change_nothing(monkeypatch, name, kw):
+    """Brute-force scenes that fit the shade kernel's LDS get no shadow launches: the shade launch answers the
+    shadow queries itself.  Same floats, bytes and ray counts as with the shadow launches (RT_INLINE_SHADOWS=0)."""
+    scene = load_scene(name).copy(**kw)
+    out = {}
+    for inline in ("1", "0"):
+        monkeypatch.setenv("RT_INLINE_SHADOWS", inline)
+        with ra.Tracer(accel=ra.RT_ACCEL_BRUTE) as t:
+            t.load_scene(scene)
+            out[inline] = t.render(want_float=True)
+    (rgb1, f1, st1), (rgb0, f0, st0) = out["1"], out["0"]
+    want = scene.max_depth + 1 if len(scene.lights) else 0          # (a scene without lights has no shadow launches either way)
+    assert st1.launches_shadow == 0 and st0.launches_shadow == want, "the switch did not switch"
+    assert np.array_equal(bits(f1), bits(f0)) and np.array_equal(rgb1, rgb0)
+    assert (st1.rays_primary, st1.rays_secondary, st1.rays_shadow) == (st0.rays_primary, st0.rays_secondary, st0.rays_shadow)
+
+
 def test_work_counters_are_optional_and_do_not_change_the_image(tracer):
     scene = load_scene("dragon").copy(width=128, height=96, spp=2)
     tracer.load_scene(scene)
