@@ -691,14 +691,16 @@ __device__ __forceinline__ void team_walk(const DScene& S, float4* wave_lds, boo
         // wave-uniform part (scalar unit): how many rays are alive, how many of the 16 node slots each gets, and
         // the list of their numbers, four bits each
         const int n = __popc(alive);
-        const int share = 16 / n;                                   // node slots per ray this round
-        const uint32_t recip = (65536u + (uint32_t)share - 1u) / (uint32_t)share;
+        // node slots per ray this round = 16 / n, and ceil(256 / that) for the lanes' division by it, from tables
+        // (n = 1 .. 8 a nibble / a byte each; nine or more rays alive: one slot each)
+        const int share = n <= 8 ? (int)((0x1112347Full >> (4 * (n - 1))) & 15ull) + 1 : 1;
+        const uint32_t recip = n <= 8 ? (uint32_t)((0x8080805640342010ull >> (8 * (n - 1))) & 255ull) : 256u;
         unsigned long long order = 0ull;
         {
             uint32_t a = alive;
             for (int i = 0; i < n; i++) { order |= (unsigned long long)__builtin_ctz(a) << (4 * i); a &= a - 1u; }
         }
-        const int k = (int)((slot * recip) >> 16);                  // = slot / share: this lane works for the k-th ray alive,
+        const int k = (int)((slot * recip) >> 8);                   // = slot / share: this lane works for the k-th ray alive,
         const int e = (int)slot - k * share;                        //   entry e of its share
         const bool mine = k < n;
         const int ray = mine ? (int)((order >> (4 * k)) & 15ull) : 0;
@@ -810,10 +812,10 @@ __device__ __forceinline__ void team_walk(const DScene& S, float4* wave_lds, boo
             if (ray_over || ray_found) nsp = 0;
             const bool first = mine && e == 0 && c == 0;                       // the ray's first lane keeps its books
             if (first) {
-                int* book = (int*)(rec + ray * TEAM_REC_F4 + 5);
-                book[0] = nsp;
-                if (ray_found) book[1] = 1;
-                if (ray_over) book[2] = 1;
+                float* book = (float*)(rec + ray * TEAM_REC_F4 + 5);     // (integers kept as float bit patterns: the record is read as float4)
+                book[0] = __int_as_float(nsp);
+                if (ray_found) book[1] = __int_as_float(1);
+                if (ray_over) book[2] = __int_as_float(1);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
