@@ -379,6 +379,31 @@ def test_shadow_queries_inside_the_shade_launch_change_nothing(monkeypatch, name
     assert (st1.rays_primary, st1.rays_secondary, st1.rays_shadow) == (st0.rays_primary, st0.rays_secondary, st0.rays_shadow)
 
 
+@pytest.mark.parametrize("name,kw", [("dragon", dict(width=192, height=128, spp=2)), ("spheres2", dict(width=160, height=120, spp=2))])
+def test_stage_times_are_optional_and_selective(name, kw):
+    """rt_set_stage_times: 0 nothing, 1 every stage, 2 only the closest-hit launches, 3 only the shadow launches;
+    the image never depends on it."""
+    scene = load_scene(name).copy(**kw)
+    with ra.Tracer() as t:
+        t.load_scene(scene)
+        frames = {}
+        for mode in (0, 1, 2, 3, 0):
+            t.set_stage_times(mode)
+            rgb, f, st = t.render(want_float=True)
+            frames.setdefault(mode, []).append((bits(f), st))
+        ref = frames[0][0][0]
+        for mode, runs in frames.items():
+            for b, st in runs:
+                assert np.array_equal(b, ref), mode
+        st0, st1, st2, st3 = frames[0][0][1], frames[1][0][1], frames[2][0][1], frames[3][0][1]
+        assert st0.ms_extend == 0 and st0.ms_shadow == 0 and st0.ms_shade == 0
+        assert st1.ms_extend > 0 and st1.ms_shade > 0 and (st1.ms_shadow > 0) == (st1.launches_shadow > 0)
+        assert st2.ms_extend > 0 and st2.ms_shadow == 0 and st2.ms_shade == 0 and st2.ms_other == 0
+        # (a brute-force scene small enough for the shade launch to answer its own shadow queries has no shadow launches)
+        assert st3.ms_extend == 0 and st3.ms_shade == 0 and st3.ms_other == 0 and (st3.ms_shadow > 0) == (st3.launches_shadow > 0)
+        assert frames[0][1][1].ms_extend == 0
+
+
 def test_work_counters_are_optional_and_do_not_change_the_image(tracer):
     scene = load_scene("dragon").copy(width=128, height=96, spp=2)
     tracer.load_scene(scene)
