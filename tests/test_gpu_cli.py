@@ -196,3 +196,24 @@ def test_progress_callback_reports_every_batch(tracer):
         assert len(seen) == n and np.array_equal(rgb, rgb2)
     assert seen[0] == (0, 200 * 100) and seen[-1] == (200 * 100, 200 * 100)
     assert len(seen) == 1 + 5 and all(a[0] < b[0] for a, b in zip(seen, seen[1:]))
+
+
+def test_c_abi_from_plain_c_writes_the_same_bmp(tmp_path):
+    """raytracer_amd/abi_example is include/rt_api.h used from C99 (gcc, no C++): parse -> create -> load -> render ->
+    BMP.  Its file must be the CLI's, byte for byte, and its ray count the library's."""
+    exe = os.path.join(ROOT, "raytracer_amd", "abi_example")
+    assert os.path.exists(exe), "raytracer_amd/abi_example not built (make -C raytracer_amd/csrc)"
+    (tmp_path / "scene.scn").write_bytes(SCENE.encode())
+    rc, out, err = run_cli(["scene.scn"], tmp_path)
+    assert rc == 0, (out, err)
+    r = subprocess.run([exe, "scene.scn", "from_c.bmp"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert (tmp_path / "from_c.bmp").read_bytes() == (tmp_path / "cli_out.bmp").read_bytes()
+    scene = ra.parse_scene_file(str(tmp_path / "scene.scn"), ref_compat=True)
+    with ra.Tracer() as t:
+        t.load_scene(scene)
+        _, _, st = t.render()
+    assert r.stdout.strip() == f"96 x 96, {st.rays} rays -> from_c.bmp"
+    # errors come back as codes with a message, the library never exits
+    r = subprocess.run([exe, "missing.scn"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "missing.scn" in r.stderr

@@ -258,3 +258,27 @@ def test_cli_debug_dump_equals_the_reference_printscene(tmp_path, rel):
     dump, _, tail = rest.partition("Beginning Trace\n")
     assert dump == want
     assert tail.endswith("Scene Trace Failed\n")
+
+
+def test_header_layout_seen_by_a_c_compiler_matches_the_ctypes_binding():
+    """abi_example is built with gcc -std=c99 from include/rt_api.h alone; its --layout dump (sizeof / offsetof of
+    every struct field) must agree with the ctypes declarations the tests and bench.py call through."""
+    import ctypes
+    import subprocess
+    from raytracer_amd import api
+    exe = os.path.join(ROOT, "raytracer_amd", "abi_example")
+    assert os.path.exists(exe), "raytracer_amd/abi_example not built (make -C raytracer_amd/csrc)"
+    out = subprocess.run([exe, "--layout"], check=True, capture_output=True, text=True).stdout.split("\n")
+    structs = {"rt_light": api.RtLight, "rt_scene_desc": api.RtSceneDesc, "rt_options": api.RtOptions, "rt_stats": api.RtStats}
+    seen = {k: set() for k in structs}
+    for line in filter(None, out):
+        name, *nums = line.split()
+        if "." not in name:
+            assert ctypes.sizeof(structs[name]) == int(nums[0]), line
+            continue
+        sname, field = name.split(".")
+        desc = getattr(structs[sname], field)
+        assert (desc.offset, desc.size) == (int(nums[0]), int(nums[1])), line
+        seen[sname].add(field)
+    for sname, st in structs.items():
+        assert seen[sname] == {f for f, _ in st._fields_}, sname
