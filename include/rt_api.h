@@ -228,6 +228,11 @@ int rt_query_rays(rt_ctx* ctx, int64_t n, const float* o, const float* d, const 
  * later renders count node / primitive fetches and tests into rt_stats; off by default.
  * The image does not depend on it. */
 int rt_set_work_counters(rt_ctx* ctx, int on);
+/* on = 0: the next rt_load_scene's first render does not time the hierarchies and walks on a sample of the
+ * frame (two to three extra frame times) but takes the choice that is right for most scenes -- for a caller
+ * that renders ONE frame per scene, as the reference's main does (src/main.cpp:56-58).  Default on.
+ * The image does not depend on it. */
+int rt_set_calibration(rt_ctx* ctx, int on);
 /* Measurement hook: on = 1 makes later renders fill rt_stats.ms_extend / ms_shadow / ms_shade /
  * ms_other (HIP events between the stage launches); on = 2 only ms_extend, on = 3 only ms_shadow (an
  * event before and after every launch of that kind: a third of the events, for frames short enough to

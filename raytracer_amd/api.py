@@ -118,6 +118,7 @@ def load_library():
         "rt_output_name": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
         "rt_write_bmp24": (C.c_int, [C.c_char_p, vp, C.c_int, C.c_int]),
         "rt_set_work_counters": (C.c_int, [vp, C.c_int]),
+        "rt_set_calibration": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared entry point
@@ -131,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_strerror", "rt_last_error", "rt_load_scene", "rt_render",
     "rt_render_device", "rt_shard_tiles", "rt_shard_bytes", "rt_render_shard", "rt_assemble_shards",
     "rt_query_rays", "rt_primary_rays", "rt_jitter_hash", "rt_parse_scene_file", "rt_free_scene",
-    "rt_output_name", "rt_write_bmp24", "rt_set_work_counters", "rt_validate_scene", "rt_set_progress_callback",
+    "rt_output_name", "rt_write_bmp24", "rt_set_work_counters", "rt_set_calibration", "rt_validate_scene", "rt_set_progress_callback",
     "rt_set_stage_times", "rt_render_multi", "rt_assemble_shards_noalloc",
 ]
 
@@ -412,6 +413,12 @@ class Tracer:
         rc = self._lib.rt_set_stage_times(self._ctx, int(on) if on in (2, 3) else (1 if on else 0))
         if rc != RT_OK:
             raise RtError(rc, "rt_set_stage_times")
+
+    def set_calibration(self, on: bool):
+        """False: no timing of hierarchies and walks at the first render after load_scene (one-frame callers)."""
+        rc = self._lib.rt_set_calibration(self._ctx, 1 if on else 0)
+        if rc != RT_OK:
+            raise RtError(rc, "rt_set_calibration")
 
     def set_progress_callback(self, fn):
         """fn(pixels_done, pixels_total) before the first and after every batch of a render; None removes it."""

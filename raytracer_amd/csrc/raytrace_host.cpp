@@ -156,6 +156,7 @@ Image* RayTrace::rayTrace(Scene& scn) {
         if (rc != RT_OK) { std::printf("%s: %s\n", rt_strerror(rc), rt_last_error()); return nullptr; }
         rt_set_stage_times(c, detailed ? 1 : 0);
         rt_set_work_counters(c, detailed ? 1 : 0);
+        rt_set_calibration(c, calibrate ? 1 : 0);      // one frame per process: timing the walks first costs more than it saves
     }
     if (debug) {
         // P1 / P2 / Plane Dist of the DEBUG build (src/raytrace.cpp:78-82): Scene::getPlaneDist and

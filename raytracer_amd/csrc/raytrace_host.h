@@ -78,13 +78,14 @@ class RayTrace {
     Image* rayTrace(Scene& scn);
     const rt_stats& stats() const { return last; }
     void setDebug(bool on) { debug = on; }           // the DEBUG build's lines of rayTrace (src/raytrace.cpp:45-47, :78-82)
+    void setCalibration(bool on) { calibrate = on; }   // time hierarchies and walks before the (one) frame; off by default here
     void setDetailedStats(bool on) { detailed = on; } // per-stage times and traversal work counts in stats()
     int gpus() const { return ngpus; }
   private:
     std::vector<rt_ctx*> ctx;
     int accel = RT_ACCEL_AUTO;
     int ngpus = 1;
-    bool debug = false, detailed = false;
+    bool debug = false, detailed = false, calibrate = false;
     rt_stats last{};
 };
 

@@ -12,6 +12,9 @@
 //   --stats             after the trace, one JSON line: rays by class, per-stage device ms,
 //                       Mrays/s, node / primitive fetches and tests per ray
 //   --stats-file PATH   the same JSON into a file instead of stdout
+//   --calibrate         time both hierarchies and every walk on a sample of the frame first and keep the
+//                       fastest per ray generation (what a library user gets by default; here one frame is
+//                       rendered per process, and the timing costs two to three frames)
 //   --debug             what the reference's DEBUG build prints: scene dump, view-plane corners,
 //                       output file name (src/main.cpp:50-53, :74-76; src/raytrace.cpp:45-47, :78-82)
 #include <chrono>
@@ -67,7 +70,7 @@ int main(int argc, char* argv[]) {
     }
     char* scenename = argv[0];
     int flags = RT_PARSE_REF_COMPAT, accel = RT_ACCEL_AUTO, film_w = 0, film_h = 0, spp = 0, gpus = 1;
-    bool stats = false, have_seed = false, stray = false, debug = false;
+    bool stats = false, have_seed = false, stray = false, debug = false, calibrate = false;
     std::string stats_file;
     unsigned seed = 1;
     for (int i = 1; i < argc; i++) {
@@ -77,6 +80,7 @@ int main(int argc, char* argv[]) {
         else if (a == "--stats") stats = true;
         else if (a == "--stats-file" && i + 1 < argc) { stats = true; stats_file = argv[++i]; }
         else if (a == "--debug") debug = true;
+        else if (a == "--calibrate") calibrate = true;
         else if (a == "--accel" && i + 1 < argc) {
             std::string v = argv[++i];
             accel = v == "brute" ? RT_ACCEL_BRUTE : v == "lbvh" ? RT_ACCEL_LBVH : RT_ACCEL_AUTO;
@@ -108,6 +112,7 @@ int main(int argc, char* argv[]) {
     RayTrace t(accel, gpus);
     t.setDebug(debug);
     t.setDetailedStats(stats);
+    t.setCalibration(calibrate);
     start = std::chrono::system_clock::now();
     Image* img = t.rayTrace(*data);
     elapsed = std::chrono::system_clock::now() - start;

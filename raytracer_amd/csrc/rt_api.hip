@@ -96,6 +96,7 @@ struct rt_ctx {
     // incoherent ones the per-lane walk); RT_PACKET_GENS / RT_PACKET_SHADOW_GENS force it.
     int8_t mode_extend[RT_MAX_GEN + 1], mode_shadow[RT_MAX_GEN + 1];
     bool tuned = false, forced_modes = false;
+    bool calibration = true;     // rt_set_calibration
     bool shade_shadowed = false; // the last batch ran without shadow launches
     bool inline_shadows = false; // brute-force scene whose primitives fit the shade kernel's LDS (RT_INLINE_SHADOWS=0 turns it off)
     bool team_walks = true;      // RT_TEAM_WALKS=0: calibration leaves the team walk out
@@ -759,7 +760,7 @@ static void adopt_tree(rt_ctx* c, bool use_alt) {
 // where the packet walk wins at scale.  Once per loaded scene.
 static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     c->tuned = true;
-    if (c->accel != RT_ACCEL_LBVH || c->forced_modes || c->tiles.empty()) {
+    if (c->accel != RT_ACCEL_LBVH || c->forced_modes || !c->calibration || c->tiles.empty()) {
         // no measurement: PLOC pays off on meshes, Karras on huge uniform clouds
         adopt_tree(c, c->S.n_prims <= (1 << 20));
         return RT_OK;
@@ -1295,6 +1296,12 @@ extern "C" int rt_set_progress_callback(rt_ctx* c, rt_progress_fn fn, void* user
 extern "C" int rt_set_stage_times(rt_ctx* c, int on) {
     if (!c) return RT_ERR_INVALID;
     c->stage_times = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
+    return RT_OK;
+}
+
+extern "C" int rt_set_calibration(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_INVALID;
+    c->calibration = on != 0;
     return RT_OK;
 }
 

@@ -214,6 +214,10 @@ def test_c_abi_from_plain_c_writes_the_same_bmp(tmp_path):
         t.load_scene(scene)
         _, _, st = t.render()
     assert r.stdout.strip() == f"96 x 96, {st.rays} rays -> from_c.bmp"
+    # the CLI renders one frame per process and skips the timing of the walks unless asked: same file either way
+    rc, out, err = run_cli(["scene.scn", "--calibrate", "--accel", "lbvh"], tmp_path)
+    assert rc == 0, (out, err)
+    assert (tmp_path / "from_c.bmp").read_bytes() == (tmp_path / "cli_out.bmp").read_bytes()
     # errors come back as codes with a message, the library never exits
     r = subprocess.run([exe, "missing.scn"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "missing.scn" in r.stderr

@@ -404,6 +404,21 @@ def test_stage_times_are_optional_and_selective(name, kw):
         assert frames[0][1][1].ms_extend == 0
 
 
+@pytest.mark.parametrize("name,kw", [("dragon", dict(width=256, height=160, spp=2)), ("plant_h_smooth", dict(width=165, height=128, spp=1, max_depth=8))])
+def test_calibration_is_optional_and_does_not_change_the_image(name, kw):
+    """rt_set_calibration(ctx, 0): no timing of hierarchies and walks before the first frame (one-frame callers);
+    same image, same ray counts."""
+    scene = load_scene(name).copy(**kw)
+    out = []
+    for on in (True, False):
+        with ra.Tracer(accel=ra.RT_ACCEL_LBVH) as t:
+            t.set_calibration(on)
+            t.load_scene(scene)
+            rgb, f, st = t.render(want_float=True)
+            out.append((rgb, bits(f), st.rays))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
 def test_work_counters_are_optional_and_do_not_change_the_image(tracer):
     scene = load_scene("dragon").copy(width=128, height=96, spp=2)
     tracer.load_scene(scene)
