@@ -380,7 +380,7 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     S = DScene{};
     S.sph = c->d_sph; S.sph_mat = c->d_sph_mat; S.tri = c->d_tri; S.tri_n = c->d_tri_n;
     S.mats = c->d_mats; S.lights = c->d_lights;
-    S.ns = s->n_spheres; S.nt = s->n_triangles; S.nl = s->n_lights; S.max_depth = s->max_depth;
+    S.ns = s->n_spheres; S.nt = s->n_triangles; S.nl = s->n_lights; S.max_depth = s->max_depth; S.nm = s->n_materials;
     S.bg = f3(s->background[0], s->background[1], s->background[2]);
     S.ambient = f3(s->ambient[0], s->ambient[1], s->ambient[2]);
     S.n_prims = S.ns + S.nt;

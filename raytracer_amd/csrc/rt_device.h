@@ -81,6 +81,7 @@ struct DScene {
     const float4* mats;      // [nm][4]  (amb, ns) (dif, ior) (spec, -) (trans, -)
     const DLight* lights;    // [nl]
     int ns, nt, nl, max_depth;
+    int nm;                  // materials
     F3 bg, ambient;
     // LBVH (valid when nodes != nullptr)
     const float4* nodes;     // [n_internal][4], see rt_lbvh.hip

@@ -1659,6 +1659,7 @@ __device__ __forceinline__ F3 refract_dir(const Spawn& sp, F3 normal, F3 irdir) 
 
 // Any-hit query against primitives that sit in LDS for the whole launch (scenes of a handful of primitives):
 // brute_trace<true> without the staging, same order, same tests.
+#define SHADE_LDS_MATS 128        // materials the shade kernels keep in LDS (8 KB); others are fetched from memory
 #define SHADE_MAX_SPH 256
 #define SHADE_MAX_TRI 128
 __device__ __forceinline__ bool resident_any_hit(const float4* sph, int ns, const float4* tri, int nt, F3 o, F3 d, float dmax) {
@@ -1691,6 +1692,14 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PHASE 
     constexpr int phase = PHASE == 3 ? 0 : PHASE;
     __shared__ float4 l_sph[PHASE == 3 ? SHADE_MAX_SPH : 1];
     __shared__ float4 l_tri[PHASE == 3 ? 3 * SHADE_MAX_TRI : 1];
+    // the materials of most scenes are a handful: kept in LDS, their fetch -- the link of the chain hit index ->
+    // hit record -> material that every hit waits for -- costs an LDS access instead of a trip to the L2
+    __shared__ float4 l_mats[PHASE == 1 ? 1 : 4 * SHADE_LDS_MATS];
+    const int cached_mats = PHASE == 1 ? 0 : (S.nm < SHADE_LDS_MATS ? S.nm : SHADE_LDS_MATS);
+    if (PHASE != 1) {
+        for (int i = threadIdx.x; i < 4 * cached_mats; i += blockDim.x) l_mats[i] = S.mats[i];
+        if (PHASE != 3) __syncthreads();
+    }
     if (PHASE == 3) {
         for (int i = threadIdx.x; i < S.ns; i += blockDim.x) l_sph[i] = S.sph[i];
         for (int i = threadIdx.x; i < 3 * S.nt; i += blockDim.x) l_tri[i] = S.tri[i];
@@ -1719,8 +1728,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PHASE 
         F3 point = f3(qp);
         F3 normal = f3(qn);
         int mat = (int)(fbits(qn.w) & 0x7FFFFFFFu);
-        const float4* M = S.mats + 4 * (size_t)mat;
-        float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+        float4 m0, m1, m2, m3;
+        if (mat < cached_mats) { m0 = l_mats[4 * mat]; m1 = l_mats[4 * mat + 1]; m2 = l_mats[4 * mat + 2]; m3 = l_mats[4 * mat + 3]; }
+        else { const float4* M = S.mats + 4 * (size_t)mat; m0 = M[0]; m1 = M[1]; m2 = M[2]; m3 = M[3]; }
         F3 dif = f3(m1), spec = f3(m2), trans = f3(m3);
         float ns = m0.w, iorf = m1.w;
         float rval = m0.x, gval = m0.y, bval = m0.z;
