@@ -219,9 +219,15 @@ int rt_assemble_shards_noalloc(rt_ctx* ctx, const void* d_all, int world, void* 
 /* -------------------------------------------------------- query utilities */
 /* Closest-hit / any-hit queries on caller-supplied rays (host pointers), used to
  * validate the LBVH against brute force.  o,d: [n][3].  dmax: [n] squared
- * distances (NULL = +inf).  accel: RT_ACCEL_BRUTE or RT_ACCEL_LBVH.
+ * distances (NULL = +inf).  accel: RT_ACCEL_BRUTE, or RT_ACCEL_LBVH / _PACKET / _WIDE / _TEAM
+ * (a walk of the hierarchy), optionally | RT_ACCEL_ALT_TREE.
  * prim_out[n]: -1 miss, else sphere index, or n_spheres + triangle index.
- * dist2_out[n] (may be NULL): squared distance of the hit. */
+ * dist2_out[n] (may be NULL): squared distance of the hit.
+ * The hierarchies are built to give the brute-force answer for rays that start where the rays of
+ * a render can start -- inside the box that holds the camera's ray origins and every primitive:
+ * what the reference's float tests accept beyond the ideal primitive grows with the distance to
+ * the ray's origin (src/raytrace.cpp:232-241), and the boxes are padded for that region.  A query
+ * whose origin lies outside it is answered by brute force whatever `accel` says. */
 int rt_query_rays(rt_ctx* ctx, int64_t n, const float* o, const float* d, const float* dmax,
                   int any_hit, int accel, int32_t* prim_out, float* dist2_out);
 /* Measurement hook (no counterpart in the reference): on != 0 makes the traversal kernels of

@@ -128,6 +128,7 @@ struct rt_ctx {
     float4* d_nodes = nullptr; int* d_prim_idx = nullptr; float4* d_leaf = nullptr;
     // second hierarchy over the same leaves (PLOC), until calibration has picked one of the two
     float4* d_nodes_alt = nullptr; int depth_alt = 0;
+    float region[6] = {0, 0, 0, 0, 0, 0};  // box of every point a ray of a render can start from (camera origins + primitives): what the hierarchies are conservative for
     // 4-wide collapses of the two hierarchies (per-lane walks only); nullptr where not built
     float4* d_wide = nullptr; float4* d_wide_alt = nullptr;
 
@@ -402,8 +403,25 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
         // with 8-bit boxes (64 B): the walks are bound by the bytes they move (K5: 68 ms against 73)
         S.wide_quant = S.n_prims > (1 << 19) ? 1 : 0;
         if (const char* e = getenv("RT_WIDE_QUANT")) S.wide_quant = atoi(e) != 0;
+        // where the camera's rays start: the eye, or the film parallelogram of an orthographic camera (src/raytrace.cpp:441-485)
+        float origin_box[6];
+        {
+            const DCamera& cam = c->cam;
+            F3 lo = cam.pos, hi = cam.pos;
+            if (cam.proj != RT_PROJ_PERSP) {
+                const F3 corner[4] = {cam.p1, cam.p1 + cam.urv, cam.p1 + cam.blv, (cam.p1 + cam.urv) + cam.blv};
+                lo = hi = corner[0];
+                for (int k = 1; k < 4; k++) {
+                    lo = f3(std::min(lo.x, corner[k].x), std::min(lo.y, corner[k].y), std::min(lo.z, corner[k].z));
+                    hi = f3(std::max(hi.x, corner[k].x), std::max(hi.y, corner[k].y), std::max(hi.z, corner[k].z));
+                }
+            }
+            origin_box[0] = lo.x; origin_box[1] = lo.y; origin_box[2] = lo.z;
+            origin_box[3] = hi.x; origin_box[4] = hi.y; origin_box[5] = hi.z;
+        }
         hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf,
-                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt, &c->d_wide, &c->d_wide_alt, S.wide_quant);
+                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt, &c->d_wide, &c->d_wide_alt, S.wide_quant,
+                                             origin_box, c->region);
         if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
         S.nodes = c->d_nodes; S.nodes4 = c->d_wide; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = 0; S.depth = depth_k;
         if (getenv("RT_VERBOSE"))
@@ -1257,6 +1275,16 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     if (accel != RT_ACCEL_BRUTE && !c->S.nodes) { rt_set_error("scene has fewer than 2 primitives: no LBVH"); return RT_ERR_UNSUPPORTED; }
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(c->device));
+    // A hierarchy is conservative for rays that start where a render's rays can start (the box of the camera's
+    // origins and all primitives): the exact tests accept more the farther away a ray starts.  Queries from
+    // outside that box are answered by brute force, which is the definition of the result.
+    std::vector<int64_t> outside;
+    if (accel != RT_ACCEL_BRUTE)
+        for (int64_t i = 0; i < n; i++) {
+            bool in = true;
+            for (int k = 0; k < 3; k++) in = in && o[3 * i + k] >= c->region[k] && o[3 * i + k] <= c->region[3 + k];
+            if (!in) outside.push_back(i);
+        }
     float *d_o = nullptr, *d_d = nullptr, *d_m = nullptr, *d_d2 = nullptr; int* d_p = nullptr;
     int rc = RT_OK;
     auto cleanup = [&]() { hipFree(d_o); hipFree(d_d); hipFree(d_m); hipFree(d_d2); hipFree(d_p); };
@@ -1283,6 +1311,22 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     Q_TRY(hipStreamSynchronize(c->stream));
 #undef Q_TRY
     cleanup();
+    if (!outside.empty()) {
+        const int64_t m = (int64_t)outside.size();
+        std::vector<float> o2(3 * m), d2(3 * m), m2(dmax ? m : 0), r2(m);
+        std::vector<int32_t> p2(m);
+        for (int64_t j = 0; j < m; j++) {
+            const int64_t i = outside[j];
+            for (int k = 0; k < 3; k++) { o2[3 * j + k] = o[3 * i + k]; d2[3 * j + k] = d[3 * i + k]; }
+            if (dmax) m2[j] = dmax[i];
+        }
+        rc = rt_query_rays(c, m, o2.data(), d2.data(), dmax ? m2.data() : nullptr, any_hit, RT_ACCEL_BRUTE, p2.data(), r2.data());
+        if (rc != RT_OK) return rc;
+        for (int64_t j = 0; j < m; j++) {
+            prim_out[outside[j]] = p2[j];
+            if (dist2_out) dist2_out[outside[j]] = r2[j];
+        }
+    }
     return rc;
 }
 

@@ -47,6 +47,11 @@ void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* 
 // LBVH over spheres + triangles (Morton codes -> radix sort -> Karras hierarchy ->
 // bottom-up refit).  Allocates *nodes ([n_prims-1][4] float4), *prim_idx ([n_prims])
 // and *leaf ([n_prims][3] float4, primitives in tree order) with hipMalloc; returns a hipError_t as int.  n_prims >= 2.
+// origin_box (lo.xyz, hi.xyz; may be null): where the camera's rays start.  The leaf boxes are padded by what the
+// exact tests can accept beyond the ideal primitive, which grows with the distance to a ray's origin; region_out
+// (may be null) receives the box of origin_box and all primitives: the hierarchy is conservative for rays that
+// start inside it, and only for those.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes,
               int** prim_idx, float4** leaf, int* depth, int ploc_radius, float4** ploc_nodes, int* ploc_depth,
-              float4** wide_nodes, float4** ploc_wide_nodes, int wide_quantised);
+              float4** wide_nodes, float4** ploc_wide_nodes, int wide_quantised, const float* origin_box,
+              float* region_out);

@@ -205,7 +205,8 @@ __device__ __forceinline__ void brute_trace(const DScene& S, float4* lds, bool a
 // ---------------------------------------------------------------- LBVH traversal
 // Node i = 16 floats: child 0 box as (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z), child 1 box
 // the same way, then (ref0, ref1, -, -).  ref >= 0: inner node; ref < 0: leaf holding
-// sorted primitive ~ref.  Boxes are padded at build time and the slab test is
+// sorted primitive ~ref.  Boxes are padded at build time by what the exact tests can
+// accept beyond the ideal primitive (rt_lbvh.hip: prim_box) and the slab test is
 // widened, so a primitive the exact test would accept is never culled; the exact
 // tests and the (distance, primitive id) lexicographic minimum then give the
 // brute-force answer whatever the visiting order.
@@ -220,7 +221,7 @@ typedef const __attribute__((address_space(4))) v4f* cv4p;
 // make inv infinite and the difference an inf - inf; a 1e-20 slope keeps the
 // arithmetic finite and means the same thing for any box of a scene (the ray stays
 // inside or outside that slab).  The box test only has to be conservative -- boxes
-// are padded by 1e-4 of their coordinates, far above this rounding -- it never
+// are padded by at least 1e-4 of their coordinates, far above this rounding -- it never
 // decides a hit.
 struct SlabRay {
     F3 inv, noi;   // 1 / d and -(o / d)

@@ -24,7 +24,7 @@ struct Box { float lo[3], hi[3]; };
 
 // Triangle record (a.xyz, ab.x)(ab.yz, ac.xy)(ac.z, ...) -> the three corners the
 // exact test spans: a, a - ab, a - ac.
-__device__ inline Box prim_box(const float4* sph, int ns, const float4* tri, int p) {
+__device__ inline Box raw_box(const float4* sph, int ns, const float4* tri, int p) {
     Box b;
     if (p < ns) {
         float4 s = sph[p];
@@ -41,16 +41,18 @@ __device__ inline Box prim_box(const float4* sph, int ns, const float4* tri, int
             b.hi[k] = fmaxf(a[k], fmaxf(v1, v2));
         }
     }
-    // pad: the exact tests accept hits a few ulps outside the ideal primitive
-    float m = 0.0f;
-    for (int k = 0; k < 3; k++) m = fmaxf(m, fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k])));
-    float pad = m * 1e-4f + 1e-30f;
-    for (int k = 0; k < 3; k++) { b.lo[k] -= pad; b.hi[k] += pad; }
     return b;
 }
 
 // order-preserving float <-> uint map so atomicMin/Max on uints reduce floats
-__device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ inline uint32_t f2ord(float f) {
+#ifdef __HIP_DEVICE_COMPILE__
+    uint32_t u = __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4);
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 __host__ __device__ inline float ord2f(uint32_t u) {
     uint32_t v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
 #ifdef __HIP_DEVICE_COMPILE__
@@ -60,12 +62,66 @@ __host__ __device__ inline float ord2f(uint32_t u) {
 #endif
 }
 
-__global__ void k_bounds(const float4* sph, int ns, const float4* tri, int n, Box* boxes, uint32_t* scene /*[6]*/) {
+// The box a walk may cull a primitive by.  It has to hold every ray the reference's exact test can ACCEPT, and
+// those tests are float arithmetic on the vector from the ray's origin to the primitive, so what they accept
+// grows with the distance E to the origin:
+//   sphere (src/raytrace.cpp:232-241): det = (d.e)^2 - |d|^2 (|e|^2 - r^2) with d.e, |e|^2, r^2 and the difference
+//     rounded to float.  With u = 2^-24 the rounding errors sum to at most 13 u |d|^2 |e|^2 + 5 u |d|^2 r^2, so
+//     det >= 0 can hold for a line that passes the centre at any distance rho with
+//     rho^2 <= r^2 (1 + 6u) + 8.4e-7 |e|^2: a sphere of radius 0.01 seen from 10 away is "hit" up to 0.013 from
+//     its centre.  The box is that of the radius sqrt(r^2 (1 + 2e-6) + 1e-6 E^2).
+//   triangle (:314-334): float determinants whose errors are about 8 u |e| |edge| |edge'|: the ray may pass an
+//     edge at a distance of 8 u E / sin(angle to the edge) = 5e-7 E / sin on the wrong side.  Padded by 2e-6 E
+//     (rays within 14 degrees of the edge they graze, and slivers, stay outside the guarantee: the bound is a
+//     worst case that sums every rounding error with the same sign).
+// E = distance from the primitive to the farthest point a ray can start from: the region spanned by the camera's
+// origins and all primitives (secondary and shadow rays start on a primitive).  The 1e-4 of the coordinates'
+// magnitude covers what the tests round in the primitive's own data.
+__device__ inline Box prim_box(const float4* sph, int ns, const float4* tri, int p, const uint32_t* region) {
+    Box b = raw_box(sph, ns, tri, p);
+    float m = 0.0f, e2 = 0.0f, h2 = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        m = fmaxf(m, fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k])));
+        float c = 0.5f * (b.lo[k] + b.hi[k]), half = 0.5f * (b.hi[k] - b.lo[k]);
+        float far = fmaxf(c - ord2f(region[k]), ord2f(region[3 + k]) - c);
+        e2 += far * far; h2 += half * half;
+    }
+    const float E = sqrtf(e2) + sqrtf(h2);
+    float pad = m * 1e-4f + 1e-30f;
+    if (p < ns) {
+        float r = fabsf(sph[p].w);
+        pad += fmaxf(sqrtf(r * r * 1.000002f + 1e-6f * E * E) - r, 0.0f);
+    } else {
+        pad += 2e-6f * E;
+    }
+    for (int k = 0; k < 3; k++) { b.lo[k] -= pad; b.hi[k] += pad; }
+    return b;
+}
+
+// region[0..5] (ordered uints, initialised with the box of the camera's ray origins) grows to hold every primitive
+__global__ void k_region(const float4* sph, int ns, const float4* tri, int n, uint32_t* region) {
     __shared__ uint32_t red[6];
     if (threadIdx.x < 6) red[threadIdx.x] = (threadIdx.x < 3) ? 0xFFFFFFFFu : 0u;
     __syncthreads();
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-        Box b = prim_box(sph, ns, tri, p);
+        Box b = raw_box(sph, ns, tri, p);
+        for (int k = 0; k < 3; k++) {
+            if (b.lo[k] == b.lo[k]) atomicMin(&red[k], f2ord(b.lo[k]));
+            if (b.hi[k] == b.hi[k]) atomicMax(&red[3 + k], f2ord(b.hi[k]));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&region[threadIdx.x], red[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&region[threadIdx.x], red[threadIdx.x]);
+}
+
+__global__ void k_bounds(const float4* sph, int ns, const float4* tri, int n, const uint32_t* region, Box* boxes,
+                         uint32_t* scene /*[6]*/) {
+    __shared__ uint32_t red[6];
+    if (threadIdx.x < 6) red[threadIdx.x] = (threadIdx.x < 3) ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        Box b = prim_box(sph, ns, tri, p, region);
         boxes[p] = b;
         for (int k = 0; k < 3; k++) {
             float c = 0.5f * (b.lo[k] + b.hi[k]);
@@ -536,12 +592,13 @@ static void collapse4(hipStream_t st, const float4* nodes, int m, bool quantised
 // by the caller.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
               int** prim_idx_out, float4** leaf_out, int* depth, int ploc_radius, float4** ploc_out,
-              int* ploc_depth, float4** wide_out, float4** ploc_wide_out, int wide_quantised) {
+              int* ploc_depth, float4** wide_out, float4** ploc_wide_out, int wide_quantised, const float* origin_box,
+              float* region_out) {
     int n = ns + nt;
     *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *ploc_out = nullptr; *ploc_depth = 0;
     *wide_out = nullptr; *ploc_wide_out = nullptr;
     if (n < 2) return (int)hipErrorInvalidValue;
-    Box* boxes = nullptr; uint32_t* scene = nullptr;
+    Box* boxes = nullptr; uint32_t* scene = nullptr;   // scene[0..5] centre bounds, [6] tree depth, [8..13] region of ray origins
     unsigned long long *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;
     int *child = nullptr, *pin = nullptr, *plf = nullptr; uint32_t* flags = nullptr; void* tmp = nullptr;
     float4* nodes = nullptr; float4* leaf = nullptr;
@@ -550,7 +607,7 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
         for (void* p : ptrs) (void)hipFree(p);
     };
     L_TRY(hipMalloc(&boxes, (size_t)n * sizeof(Box)));
-    L_TRY(hipMalloc(&scene, 8 * sizeof(uint32_t)));
+    L_TRY(hipMalloc(&scene, 16 * sizeof(uint32_t)));
     L_TRY(hipMalloc(&keys, (size_t)n * 8)); L_TRY(hipMalloc(&keys2, (size_t)n * 8));
     L_TRY(hipMalloc(&vals, (size_t)n * 4)); L_TRY(hipMalloc(&vals2, (size_t)n * 4));
     L_TRY(hipMalloc(&child, (size_t)(n - 1) * 2 * sizeof(int)));
@@ -559,11 +616,15 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     L_TRY(hipMalloc(&flags, (size_t)(n - 1) * sizeof(uint32_t)));
     L_TRY(hipMalloc(&nodes, (size_t)(n - 1) * 4 * sizeof(float4)));
     L_TRY(hipMalloc(&leaf, (size_t)n * 3 * sizeof(float4)));
-    uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};   // [6] = tree depth
+    uint32_t init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    for (int k = 0; k < 6 && origin_box; k++)
+        if (origin_box[k] == origin_box[k]) init[8 + k] = f2ord(origin_box[k]);
     L_TRY(hipMemcpyAsync(scene, init, sizeof(init), hipMemcpyHostToDevice, st));
+    L_TRY(hipStreamSynchronize(st));                                                // init is a local
     L_TRY(hipMemsetAsync(flags, 0, (size_t)(n - 1) * sizeof(uint32_t), st));
     int blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, sph, ns, tri, n, boxes, scene);
+    hipLaunchKernelGGL(k_region, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, sph, ns, tri, n, scene + 8);
+    hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, sph, ns, tri, n, scene + 8, boxes, scene);
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, st, boxes, n, scene, keys, vals);
     L_TRY(hipMalloc(&tmp, rts_sort_temp_bytes((size_t)n)));
     {
@@ -584,10 +645,12 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, st, keys2, n, child, pin, plf);
     hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, boxes, vals2, n, child, pin, plf, flags, nodes);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, st, pin, plf, n, scene + 6);
-    uint32_t dpt = 0;
+    uint32_t dpt = 0, reg[6] = {0, 0, 0, 0, 0, 0};
     L_TRY(hipMemcpyAsync(&dpt, scene + 6, sizeof(dpt), hipMemcpyDeviceToHost, st));
+    L_TRY(hipMemcpyAsync(reg, scene + 8, sizeof(reg), hipMemcpyDeviceToHost, st));
     L_TRY(hipStreamSynchronize(st));
     *depth = (int)dpt;
+    for (int k = 0; k < 6 && region_out; k++) region_out[k] = ord2f(reg[k]);
     if (ploc_radius > 0) {
         float4* pn = nullptr;
         int r = 0, d = 0;

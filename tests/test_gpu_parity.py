@@ -162,6 +162,9 @@ TREE_WALKS = (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE, 
 
 
 def _random_rays(scene, n, rng):
+    """Rays aimed at the primitives.  Four in five start inside the box of the primitives, where the rays of a
+    render start and for which the hierarchies are built to be conservative; the rest start up to an extent
+    outside it, where a query is answered by brute force whatever walk was asked for."""
     prim_pts = []
     if len(scene.spheres):
         prim_pts.append(scene.spheres[:, :3])
@@ -170,10 +173,12 @@ def _random_rays(scene, n, rng):
     pts = np.concatenate(prim_pts)
     lo, hi = pts.min(0), pts.max(0)
     ext = np.maximum(hi - lo, 1e-3)
-    o = (lo - ext) + rng.random((n, 3)) * 3 * ext
+    o = lo + rng.random((n, 3)) * (hi - lo)
+    far = rng.random(n) < 0.2
+    o[far] = ((lo - ext) + rng.random((n, 3)) * 3 * ext)[far]
     tgt = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.02, (n, 3)) * ext
     d = tgt - o
-    d *= rng.uniform(0.2, 3.0, (n, 1)) / np.linalg.norm(d, axis=1, keepdims=True)   # un-normalised on purpose
+    d *= rng.uniform(0.2, 3.0, (n, 1)) / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)   # un-normalised on purpose
     return o.astype(np.float32), d.astype(np.float32)
 
 
