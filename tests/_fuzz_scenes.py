@@ -15,12 +15,13 @@ def _unit(v):
     return v / n if n > 0 else np.array([0.0, 0.0, 1.0])
 
 
-def random_scene(seed):
-    rng = np.random.default_rng(1000 + seed)
+def random_scene(seed, big=False):
+    """big: thousands of primitives and films of up to 256 x 160 (deep hierarchies, many packets; seconds of oracle time)"""
+    rng = np.random.default_rng((1000 if not big else 500000) + seed)
     scale = float(10.0 ** rng.choice([-3, -1, 0, 0, 1, 3]))
     offset = rng.normal(size=3) * scale * float(rng.choice([0, 0, 1, 30, 1000]))
-    n_sph = int(rng.choice([0, 1, 5, 40, 200]))
-    n_tri = int(rng.choice([0, 1, 12, 100, 400]))
+    n_sph = int(rng.choice([0, 1, 5, 40, 200] if not big else [0, 300, 2000, 6000]))
+    n_tri = int(rng.choice([0, 1, 12, 100, 400] if not big else [0, 500, 5000, 20000]))
     if n_sph + n_tri == 0:
         n_sph = 3
     n_mat = int(rng.integers(1, 9))
@@ -101,10 +102,36 @@ def random_scene(seed):
         l64[:, 1:4] = np.where(l64[:, 0:1] == 1, l64[:, 1:4], l64[:, 1:4] * S * S)   # inverse-square lights keep their brightness
         lights = l64.astype(np.float32)
     proj = ra.RT_PROJ_PERSP if rng.random() < 0.8 else 1 - ra.RT_PROJ_PERSP
+    width, height = int(rng.integers(1, 97 if not big else 257)), int(rng.integers(1, 65 if not big else 161))
+    spp = int(rng.choice([1, 1, 2, 3, 5]))
+    max_depth = int(rng.choice([0, 1, 2, 5, 5, 7]))
+    jitter_seed = int(rng.integers(1, 1 << 30))
+    # rarer cases, for seeds from 20000 on (the scenes of lower seeds stay what they were when findings were
+    # recorded under their numbers), drawn from a stream of their own
+    odd = np.random.default_rng(7000 + seed)
+    rare = (lambda p: odd.random() < p) if seed >= 20000 else (lambda p: False)
+    cam64 = cam_pos * S + offset
+    if rare(0.1) and n_sph:                       # spheres of radius zero and below
+        pick = odd.random(n_sph) < 0.3
+        sph64[pick, 3] *= odd.choice([0.0, -1.0], int(pick.sum()))
+    if rare(0.1) and n_sph:                                # the eye inside a sphere
+        k = int(np.argmax(np.abs(sph64[:, 3])))
+        cam64 = sph64[k, 0:3] + odd.normal(size=3) * 0.2 * abs(sph64[k, 3])
+    if rare(0.12):                                         # long chains of mirror bounces: many thin generations
+        max_depth = int(odd.choice([12, 25]))
+        mats[:, 6:9] = odd.uniform(0.3, 0.9, (n_mat, 3))
+        mats[:, 10:13] = 0
+    if rare(0.1):                                          # many lights: one shadow query per hit and light
+        extra = []
+        for _ in range(int(odd.integers(5, 10))):
+            kind = int(odd.integers(1, 4))
+            pos = (centres[odd.integers(0, n_clusters)] + odd.normal(size=3) * 5.0) * S + offset
+            col = odd.uniform(0.05, 0.3, 3) if kind == 1 else odd.uniform(2, 20, 3) * S * S
+            extra.append([kind, *col, *pos, *_unit(odd.normal(size=3)), float(odd.uniform(0.1, 1.0)), float(odd.uniform(1.0, 1.6))])
+        lights = np.concatenate([np.asarray(lights, np.float32).reshape(-1, 12), np.array(extra, np.float32)])
     return ra.SceneArrays(
-        width=int(rng.integers(1, 97)), height=int(rng.integers(1, 65)), spp=int(rng.choice([1, 1, 2, 3, 5])),
-        max_depth=int(rng.choice([0, 1, 2, 5, 5, 7])), proj=int(proj), seed=int(rng.integers(1, 1 << 30)),
-        cam_pos=(cam_pos * S + offset).astype(np.float32), cam_dir=cam_dir.astype(np.float32), cam_up=up.astype(np.float32),
+        width=width, height=height, spp=spp, max_depth=max_depth, proj=int(proj), seed=jitter_seed,
+        cam_pos=cam64.astype(np.float32), cam_dir=cam_dir.astype(np.float32), cam_up=up.astype(np.float32),
         cam_half_angle=float(np.float32(rng.uniform(0.15, 1.0))),
         background=rng.random(3).astype(np.float32), ambient=(rng.random(3) * 0.4).astype(np.float32),
         spheres=sph64.astype(np.float32), sphere_mat=rng.integers(0, n_mat, n_sph).astype(np.int32),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the HIP path against the CPU oracle on seeded random scenes.
 
-  python tools/fuzz_parity.py [--seeds A B] [--trees] [--save]
+  python tools/fuzz_parity.py [--seeds A B] [--trees] [--big] [--save]
 
 For every seed: the oracle's frame, then the HIP path by brute force and through the hierarchy with every walk
 forced in turn (and, with --trees, on both hierarchies): two frames per context (the second runs its thin
@@ -60,6 +60,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs=2, default=[0, 40])
     ap.add_argument("--trees", action="store_true", help="force each hierarchy (Karras, PLOC) in turn as well")
+    ap.add_argument("--big", action="store_true", help="thousands of primitives, larger films (seconds of oracle time per seed)")
     ap.add_argument("--save", action="store_true", help="write the frames of a mismatch to gpurun_out/fuzz_<seed>_<variant>.npz")
     args = ap.parse_args()
     orc = Oracle()
@@ -67,7 +68,7 @@ def main():
     transient = []
     t0 = time.time()
     for seed in range(*args.seeds):
-        scene = random_scene(seed)
+        scene = random_scene(seed, big=args.big)
         orgb, orgbf, cnt, _ = orc.render(scene, threads=16)
         variants = [("brute", ra.RT_ACCEL_BRUTE, {})]
         for walk, env in WALKS.items():
