@@ -500,6 +500,36 @@ def test_k5_full_scene_and_film_against_oracle_crops(oracle, x0, y0, shard):
             assert np.array_equal(tile, rgb[ty * ra.RT_TILE:(ty + 1) * ra.RT_TILE, tx * ra.RT_TILE:(tx + 1) * ra.RT_TILE]), (x0, y0)
 
 
+def test_k5_full_scale_camera_and_surface_rays_every_walk_equals_brute_force():
+    """The 11 M-primitive scene, rays as a render sends them: 40 000 primary rays of random pixels (the eye is
+    hundreds of units from every sphere, where the reference's float sphere test accepts rays that pass a sphere
+    of radius 0.05 several radii from its centre -- the leaf boxes have to hold those) and the rays that leave
+    their hit points towards random primitives.  Brute force on the GPU (11 M exact tests per ray) is the
+    reference's answer; every walk of both hierarchies must return the same primitive and distance bits."""
+    from raytracer_amd.synth import synthetic_scene
+    scene = synthetic_scene(scale=1.0).copy(spp=1)
+    rng = np.random.default_rng(23)
+    n = 40_000
+    with ra.Tracer(accel=ra.RT_ACCEL_LBVH) as t:
+        t.load_scene(scene)
+        o, d = t.primary_rays(rng.integers(0, scene.width, n), rng.integers(0, scene.height, n), np.zeros(n, np.int32))
+        pb, db = t.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
+        assert (pb >= 0).mean() > 0.5 and (pb[pb >= 0] < len(scene.spheres)).any()
+        hit = pb >= 0
+        tpar = np.sqrt(db[hit].astype(np.float64) / (d[hit].astype(np.float64) ** 2).sum(1))
+        o2 = (o[hit] + d[hit] * tpar[:, None]).astype(np.float32)
+        tgt = scene.spheres[rng.integers(0, len(scene.spheres), len(o2)), :3]
+        d2 = (tgt - o2 + rng.normal(0, 0.3, o2.shape)).astype(np.float32)
+        pb2, db2 = t.query_rays(o2, d2, accel=ra.RT_ACCEL_BRUTE)
+        for accel in TREE_WALKS:
+            pl, dl = t.query_rays(o, d, accel=accel)
+            assert np.array_equal(pb, pl), f"walk {accel}, camera rays: {(pb != pl).sum()} of {n} closest hits differ"
+            assert np.array_equal(bits(db[hit]), bits(dl[hit]))
+            pl2, dl2 = t.query_rays(o2, d2, accel=accel)
+            assert np.array_equal(pb2, pl2), f"walk {accel}, surface rays: {(pb2 != pl2).sum()} of {len(o2)} closest hits differ"
+            assert np.array_equal(bits(db2[pb2 >= 0]), bits(dl2[pb2 >= 0]))
+
+
 def test_coincident_primitives_and_tie_rules(oracle, monkeypatch):
     """Thousands of primitives at the same place: every box overlaps every other (the second hierarchy
     degenerates and is rejected), and every ray meets many primitives at exactly the same distance, where
