@@ -469,6 +469,25 @@ def test_k3_full_size_frame_against_oracle_crops_and_across_partitions(oracle):
         assert np.array_equal(whole.cpu().numpy().reshape(scene.height, scene.width, 3), rgb)
 
 
+def test_k3_full_size_frame_by_brute_force_equals_the_hierarchy():
+    """The bench frame itself (3840x2160, 16 spp, 353 M rays) rendered twice: with every ray tested against all
+    10 002 primitives (the reference's `intersect`, five seconds on the GPU) and through the hierarchy.  All
+    8.3 M pixels must have the same float bits and the ray counts must agree."""
+    scene = load_scene("dragon").copy(width=3840, height=2160, spp=16, seed=1)
+    frames = {}
+    for label, accel in (("hierarchy", ra.RT_ACCEL_LBVH), ("brute force", ra.RT_ACCEL_BRUTE)):
+        with ra.Tracer(accel=accel) as t:
+            t.load_scene(scene)
+            frames[label] = t.render(want_float=True)
+    (rgb_h, f_h, st_h), (rgb_b, f_b, st_b) = frames["hierarchy"], frames["brute force"]
+    differ = int((bits(f_h) != bits(f_b)).any(axis=2).sum())
+    REPORT["K3 full frame, hierarchy against brute force on the GPU"] = {"pixels": int(f_h.shape[0] * f_h.shape[1]),
+                                                                         "float_bit_identical": 1.0 - differ / (f_h.shape[0] * f_h.shape[1])}
+    assert differ == 0, f"{differ} pixels differ in float"
+    assert np.array_equal(rgb_h, rgb_b)
+    assert (st_h.rays_primary, st_h.rays_secondary, st_h.rays_shadow) == (st_b.rays_primary, st_b.rays_secondary, st_b.rays_shadow)
+
+
 @pytest.mark.parametrize("x0,y0,shard", [(3840, 2160, True), (3012, 1796, True), (4700, 2500, False), (2200, 2900, False)])
 def test_k5_full_scene_and_film_against_oracle_crops(oracle, x0, y0, shard):
     """The synthetic scene at full scale (10^6 spheres + 10^7 triangles) on the full 7680x4320 film, 2 spp.
