@@ -79,7 +79,12 @@ struct Stream {
         }
         std::string tmp(s, q - s);
         p = q;
-        return std::strtof(tmp.c_str(), nullptr);
+        // out of range: the extraction stores the largest finite value of that sign and fails (std::num_get,
+        // [facet.num.get.virtuals]); a value too small for a float is stored as strtof rounds it, without failing
+        const float v = std::strtof(tmp.c_str(), nullptr);
+        if (v == HUGE_VALF) { failed = true; return 3.402823466e+38f; }
+        if (v == -HUGE_VALF) { failed = true; return -3.402823466e+38f; }
+        return v;
     }
     // `scn >> int`
     int number_i() {

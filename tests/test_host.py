@@ -130,6 +130,22 @@ def test_parser_stream_quirks(tmp_path):
     assert (s.max_depth, s.spp) == (5, 2)
 
 
+def test_parser_number_out_of_float_range(tmp_path):
+    """`scn >> float` on 1e39: the largest finite float of that sign is stored and the stream fails, which ends
+    the parse (std::num_get; src/parse.cpp:102 `while (scn >> str)`); a value too small for a float is rounded
+    (to zero here) and parsing goes on."""
+    p = tmp_path / "range.scn"
+    p.write_text("ambient_light .0068 15. 1e39\nbackground 1 2 3\n")
+    s = ra.parse_scene_file(str(p))
+    assert s.ambient.tolist() == [np.float32(.0068), 15.0, np.finfo(np.float32).max] and s.background.tolist() == [0, 0, 0]
+    p.write_text("ambient_light .5 -1e39 7\nbackground 1 2 3\n")
+    s = ra.parse_scene_file(str(p))
+    assert s.ambient.tolist() == [0.5, -np.finfo(np.float32).max, 0.0] and s.background.tolist() == [0, 0, 0]
+    p.write_text("ambient_light .5 1e-50 7\nbackground 1 2 3\n")
+    s = ra.parse_scene_file(str(p))
+    assert s.ambient.tolist() == [0.5, 0.0, 7.0] and s.background.tolist() == [1, 2, 3]
+
+
 def test_output_name_rule():
     assert ra.output_name("dragon.bmp") == "dragon.bmp"
     assert ra.output_name("a.bmp.tail") == "a.bmp"

@@ -97,3 +97,27 @@ def test_spot_light_falloff_branches_match(ref, oracle, tmp_path, w, h, spp):
     b = ra.parse_scene_file(str(p), ref_compat=True)
     assert np.array_equal(bits(b.lights), bits(scene.lights)) and (b.width, b.height) == (160, 160)
     assert b.output_name == "spot_falloff.bmp.tail"
+
+
+def test_generated_scene_text_parses_like_the_reference(ref, tmp_path):
+    """The parser fuzzer's generator (tools/fuzz_parser.py: every number spelling the stream extraction accepts or
+    rejects, out-of-range values, tabs, CRLF, comments, unknown words, directives one argument short or with
+    too many, indices in and out of range), 400 seeds: same success or failure, same arrays bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_parser import compare, scene_text
+    path = str(tmp_path / "fuzz.scn")
+    parsed = 0
+    for seed in range(400):
+        with open(path, "w", newline="") as f:
+            f.write(scene_text(seed))
+        rc = ref.load(path)
+        try:
+            b = ra.parse_scene_file(path, ref_compat=True)
+        except ra.RtError:
+            assert rc < 0, f"seed {seed}: the reference parses what the product rejects"
+            continue
+        assert rc > 0, f"seed {seed}: the product parses what the reference rejects"
+        assert compare(ref.scene_arrays(), b) == [], f"seed {seed}"
+        parsed += 1
+    assert parsed > 300
