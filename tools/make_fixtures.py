@@ -89,7 +89,7 @@ def scene_to_scn(s: ra.SceneArrays, per_vertex_normals=None) -> str:
     for i, sp in enumerate(s.spheres):
         mat(int(s.sphere_mat[i]))
         out.append("sphere " + " ".join(f9(v) for v in sp))
-    nv = 0
+    nv = nn = 0          # vertices and normals are pools of their own, indexed in order of appearance
     for i, tv in enumerate(s.tri_verts):
         mat(int(s.tri_mat[i]))
         for k in range(3):
@@ -100,12 +100,14 @@ def scene_to_scn(s: ra.SceneArrays, per_vertex_normals=None) -> str:
                 # a degenerate normal is written as 0 0 0: the parser's norm() turns it
                 # into NaN, as it does for the flat normal of a zero-area triangle
                 out.append("normal " + (" ".join(f9(v) for v in nk) if np.all(np.isfinite(nk)) else "0 0 0"))
-            out.append(f"normal_triangle {nv} {nv + 1} {nv + 2} {nv} {nv + 1} {nv + 2}")
+            out.append(f"normal_triangle {nv} {nv + 1} {nv + 2} {nn} {nn + 1} {nn + 2}")
+            nn += 3
         elif s.tri_flags[i]:
             for k in range(3):
                 nk = s.tri_normals[i, 3 * k:3 * k + 3]
                 out.append("normal " + (" ".join(f9(v) for v in nk) if np.all(np.isfinite(nk)) else "0 0 0"))
-            out.append(f"normal_triangle {nv} {nv + 1} {nv + 2} {nv} {nv + 1} {nv + 2}")
+            out.append(f"normal_triangle {nv} {nv + 1} {nv + 2} {nn} {nn + 1} {nn + 2}")
+            nn += 3
         else:
             out.append(f"triangle {nv} {nv + 1} {nv + 2}")
         nv += 3
