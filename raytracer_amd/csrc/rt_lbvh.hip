@@ -77,6 +77,9 @@ __host__ __device__ inline float ord2f(uint32_t u) {
 // E = distance from the primitive to the farthest point a ray can start from: the region spanned by the camera's
 // origins and all primitives (secondary and shadow rays start on a primitive).  The 1e-4 of the coordinates'
 // magnitude covers what the tests round in the primitive's own data.
+#ifndef RT_TRI_PAD_PER_DISTANCE
+#define RT_TRI_PAD_PER_DISTANCE 2e-6f
+#endif
 __device__ inline Box prim_box(const float4* sph, int ns, const float4* tri, int p, const uint32_t* region) {
     Box b = raw_box(sph, ns, tri, p);
     float m = 0.0f, e2 = 0.0f, h2 = 0.0f;
@@ -92,7 +95,7 @@ __device__ inline Box prim_box(const float4* sph, int ns, const float4* tri, int
         float r = fabsf(sph[p].w);
         pad += fmaxf(sqrtf(r * r * 1.000002f + 1e-6f * E * E) - r, 0.0f);
     } else {
-        pad += 2e-6f * E;
+        pad += RT_TRI_PAD_PER_DISTANCE * E;
     }
     for (int k = 0; k < 3; k++) { b.lo[k] -= pad; b.hi[k] += pad; }
     return b;

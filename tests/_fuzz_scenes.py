@@ -146,3 +146,47 @@ WALKS = {
     "lane-wide": {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0", "RT_LANE_WIDE": "1"},
     "team": {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0", "RT_LANE_WIDE": "2"},
 }
+
+
+def edge_grazing_case(trial, n=400_000, nt=400):
+    """A sparse cloud of small triangles (every second trial: triangles lying in a coordinate plane, whose boxes have
+    no thickness; every third: rays nearly in the triangle's plane) and n rays aimed within a few float roundings
+    of an edge or a vertex of a random triangle, from origins up to thousands of units away -- the zone where the
+    reference's float determinants decide by rounding.  Two far triangles stretch the region rays may start from.
+    -> (scene, origins [n,3] float32, directions [n,3] float32)"""
+    rng = np.random.default_rng(100 + trial)
+    c = rng.uniform(-1, 1, (nt, 3))
+    size = 10.0 ** rng.uniform(-3.0, -1.0, nt)
+    v = c[:, None, :] + rng.normal(size=(nt, 3, 3)) * size[:, None, None]
+    if trial % 2 == 1:
+        ax = rng.integers(0, 3, nt)
+        v[np.arange(nt), 1, ax] = v[np.arange(nt), 0, ax]
+        v[np.arange(nt), 2, ax] = v[np.arange(nt), 0, ax]
+    far = float(10.0 ** rng.uniform(1, 3.5))
+    v[0] = np.array([[far, far, far], [far + 1, far, far], [far, far + 1, far]])
+    v[1] = -v[0]
+    tv = v.reshape(nt, 9).astype(np.float32)
+    vf = tv.reshape(nt, 3, 3).astype(np.float64)
+    fn = np.cross(vf[:, 1] - vf[:, 0], vf[:, 2] - vf[:, 0])
+    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-300)
+    scene = ra.SceneArrays(width=8, height=8, tri_verts=tv, tri_normals=np.tile(fn, (1, 3)).astype(np.float32),
+                           tri_flags=np.zeros(nt, np.int32), tri_mat=np.zeros(nt, np.int32),
+                           cam_pos=np.array([0, 0, -5], np.float32)).normalise()
+    k = rng.integers(2, nt, n)
+    e = rng.integers(0, 3, n)
+    a, b = vf[k, e], vf[k, (e + 1) % 3]
+    s = np.where(rng.random(n) < 0.3, rng.integers(0, 2, n).astype(np.float64), rng.random(n))
+    p = a + (b - a) * s[:, None]
+    dist = 10.0 ** rng.uniform(0, np.log10(far), n)
+    dirn = rng.normal(size=(n, 3))
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    if trial % 3 == 2:
+        dirn -= fn[k] * (np.einsum("ij,ij->i", dirn, fn[k]) * rng.uniform(0.9, 1.0, n))[:, None]
+        dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    o = np.clip(p - dirn * dist[:, None], -far, far + 1)       # inside the region the hierarchy is built for
+    off = rng.normal(size=(n, 3))
+    off -= dirn * np.einsum("ij,ij->i", off, dirn)[:, None]
+    off /= np.maximum(np.linalg.norm(off, axis=1, keepdims=True), 1e-300)
+    tgt = p + off * (rng.uniform(-4, 4, n) * 6e-8 * np.linalg.norm(p - o, axis=1))[:, None]
+    d = (tgt - o) * rng.uniform(0.3, 2.0, (n, 1))
+    return scene, o.astype(np.float32), d.astype(np.float32)

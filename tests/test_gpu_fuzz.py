@@ -10,8 +10,8 @@ import numpy as np
 import pytest
 
 import raytracer_amd as ra
-from _fuzz_scenes import WALKS, random_scene
-from conftest import same_float_image
+from _fuzz_scenes import WALKS, edge_grazing_case, random_scene
+from conftest import bits, same_float_image
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +92,21 @@ def test_tiny_spheres_far_from_the_eye_are_hit_where_the_reference_hits_them(ora
         same = _same(rgbf, orgbf, label)
         assert same.all(), f"{label}: {int((~same).sum())} of {same.size} pixels differ in float"
         assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (cnt.primary, cnt.secondary, cnt.shadow), label
+
+
+@pytest.mark.parametrize("trial", [1, 2, 4, 5, 9])
+def test_rays_grazing_triangle_edges_from_far_origins(trial):
+    """Rays aimed within a few float roundings of triangle edges from up to thousands of units away: whether the
+    reference's float determinants (src/raytrace.cpp:314-334) call them hits is rounding, brute force on the GPU
+    follows the reference, and a leaf box may cull none of them.  (Boxes padded by 1e-4 of the coordinates alone lose
+    hits on trials 1 and 9: triangles in a coordinate plane seen from 500 units.)"""
+    scene, o, d = edge_grazing_case(trial)
+    with ra.Tracer(accel=ra.RT_ACCEL_LBVH) as t:
+        t.load_scene(scene)
+        pb, db = t.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
+        assert 0.2 < (pb >= 0).mean() < 0.8, "the rays are meant to sit on the edge between hit and miss"
+        for walk in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_TEAM,
+                     ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE):
+            pl, dl = t.query_rays(o, d, accel=walk)
+            assert np.array_equal(pb, pl), f"walk {walk}: {(pb != pl).sum()} of {len(pb)} closest hits differ"
+            assert np.array_equal(bits(db[pb >= 0]), bits(dl[pb >= 0]))
