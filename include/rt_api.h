@@ -239,6 +239,14 @@ int rt_set_work_counters(rt_ctx* ctx, int on);
  * that renders ONE frame per scene, as the reference's main does (src/main.cpp:56-58).  Default on.
  * The image does not depend on it. */
 int rt_set_calibration(rt_ctx* ctx, int on);
+/* Replay of thin batches as HIP graphs.  A batch of at most 16 Mi samples whose launches repeat those of an earlier
+ * batch of the context (same scene, film, partition, output buffer and choice of walks) is captured into a graph the
+ * second time and launched as one from then on: such a frame is a chain of dozens of launches that takes the host
+ * about as long to queue as the device to run.  on = 0 turns it off (and drops the graphs), 1 on (the default),
+ * negative leaves it as it is; replays, if not NULL, receives the number of batches of this context that ran as a
+ * graph launch so far.  Not used while stage times are taken.  The image does not depend on it.
+ * No counterpart in the reference (its frame loop has no launches to queue, src/raytrace.cpp:92-122). */
+int rt_set_graphs(rt_ctx* ctx, int on, uint64_t* replays);
 /* Measurement hook: on = 1 makes later renders fill rt_stats.ms_extend / ms_shadow / ms_shade /
  * ms_other (HIP events between the stage launches); on = 2 only ms_extend, on = 3 only ms_shadow (an
  * event before and after every launch of that kind: a third of the events, for frames short enough to

@@ -119,6 +119,7 @@ def load_library():
         "rt_write_bmp24": (C.c_int, [C.c_char_p, vp, C.c_int, C.c_int]),
         "rt_set_work_counters": (C.c_int, [vp, C.c_int]),
         "rt_set_calibration": (C.c_int, [vp, C.c_int]),
+        "rt_set_graphs": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared entry point
@@ -133,7 +134,7 @@ EXPORTED_SYMBOLS = [
     "rt_render_device", "rt_shard_tiles", "rt_shard_bytes", "rt_render_shard", "rt_assemble_shards",
     "rt_query_rays", "rt_primary_rays", "rt_jitter_hash", "rt_parse_scene_file", "rt_free_scene",
     "rt_output_name", "rt_write_bmp24", "rt_set_work_counters", "rt_set_calibration", "rt_validate_scene", "rt_set_progress_callback",
-    "rt_set_stage_times", "rt_render_multi", "rt_assemble_shards_noalloc",
+    "rt_set_stage_times", "rt_render_multi", "rt_assemble_shards_noalloc", "rt_set_graphs",
 ]
 
 
@@ -419,6 +420,15 @@ class Tracer:
         rc = self._lib.rt_set_calibration(self._ctx, 1 if on else 0)
         if rc != RT_OK:
             raise RtError(rc, "rt_set_calibration")
+
+    def set_graphs(self, on=None) -> int:
+        """Replay of thin batches as HIP graphs: True / False turns it on / off, None leaves it; returns how many
+        batches of this context ran as a graph launch so far."""
+        n = C.c_uint64(0)
+        rc = self._lib.rt_set_graphs(self._ctx, -1 if on is None else (1 if on else 0), C.byref(n))
+        if rc != RT_OK:
+            raise RtError(rc, "rt_set_graphs")
+        return int(n.value)
 
     def set_progress_callback(self, fn):
         """fn(pixels_done, pixels_total) before the first and after every batch of a render; None removes it."""

@@ -151,9 +151,27 @@ struct rt_ctx {
     uint8_t* d_shard = nullptr; size_t shard_cap = 0;      // rt_render_multi: this context's shard
     uint8_t* d_all = nullptr; size_t all_cap = 0;          // rt_render_multi, context 0: every shard
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // Thin batches replayed as HIP graphs: a frame of a few hundred microseconds is a chain of dozens of launches, and
+    // queueing them one by one costs the host about as long as the device needs to run them.  A batch whose launches
+    // would be the same as those of an earlier batch (same arguments by value: scene, pool, camera, tiles, walks,
+    // stream split) is captured the second time it comes and replayed from then on.  RT_GRAPHS=0 turns it off,
+    // RT_GRAPH_SAMPLES=n moves the size limit (batches of more samples are queued directly: their enqueue time is hidden).
+    struct BatchGraph { std::vector<uint8_t> key; int seen = 0; bool failed = false; hipGraphExec_t exec = nullptr; };
+    std::vector<BatchGraph> graphs;
+    bool graphs_on = true;
+    uint64_t graph_max_samples = 16u << 20;
+    uint64_t graph_replays = 0;    // batches of this context that ran as a graph launch
 };
 
+static void drop_graphs(rt_ctx* c) {
+    for (auto& g : c->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
 static void free_scene(rt_ctx* c) {
+    drop_graphs(c);
     hipFree(c->d_sph); hipFree(c->d_sph_mat); hipFree(c->d_tri); hipFree(c->d_tri_n);
     hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_nodes_alt); hipFree(c->d_wide); hipFree(c->d_wide_alt); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
     c->d_sph = nullptr; c->d_sph_mat = nullptr; c->d_tri = nullptr; c->d_tri_n = nullptr;
@@ -189,6 +207,8 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     if (const char* e = getenv("RT_STAGE_TIMES")) c->stage_times = (atoi(e) == 2 || atoi(e) == 3) ? atoi(e) : 1;
     if (const char* e = getenv("RT_OVERLAP_RAYS")) c->overlap_rays = strtoull(e, nullptr, 10);
     if (const char* e = getenv("RT_TEAM_WALKS")) c->team_walks = atoi(e) != 0;
+    if (const char* e = getenv("RT_GRAPHS")) c->graphs_on = atoi(e) != 0;
+    if (const char* e = getenv("RT_GRAPH_SAMPLES")) c->graph_max_samples = strtoull(e, nullptr, 10);
     if (const char* e = getenv("RT_PACKET_GENS")) {
         c->forced_modes = true;
         // RT_LANE_WIDE: the other generations walk the 4-wide tree per lane (1) or per team of lanes (2)
@@ -225,6 +245,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    drop_graphs(c);
     free_scene(c);
     free_pool(c);
     hipFree(c->d_counters); hipFree(c->d_tiles); hipFree(c->d_rowbase); hipFree(c->d_rgb); hipFree(c->d_rgbf);
@@ -618,19 +639,16 @@ static int ensure_overlap(rt_ctx* c) {
     return RT_OK;
 }
 
-// Enqueues one batch (tiles [tile0, tile0+ntiles) of the current partition) and
-// waits for it.  All launches are asynchronous; the only host sync is the final
-// read of the counters (overflow flag + ray statistics).
-static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode, uint8_t* d_out, float* d_outf,
-                     BatchResult& res, StageTimes& tm) {
+// Queues the launches of one batch on the context's streams (or, while stream A is being captured, into the graph).
+static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode, uint8_t* d_out, float* d_outf,
+                         int first_ov, StageTimes& tm, StageTimes& tmB) {
     const DScene& S = c->S;
-    const uint32_t spp = (uint32_t)c->cam.spp;
     const uint32_t npixels = ntiles * RT_TILE_AREA;
-    const uint64_t nsamples64 = (uint64_t)npixels * spp;
-    const uint32_t nsamples = (uint32_t)nsamples64;
+    const uint32_t nsamples = (uint32_t)((uint64_t)npixels * (uint32_t)c->cam.spp);
     hipStream_t st = c->stream;
+    hipStream_t B = c->stream2;
     const uint64_t cap = c->P.capacity;
-    const auto host_t0 = std::chrono::steady_clock::now();
+    const bool any_ov = first_ov <= S.max_depth;
     tm.mark(3);
     rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1, c->count_work || S.profile);
     tm.mark(3);
@@ -646,22 +664,6 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     // hits) runs on B, in generation order, after the lighting of g - 1.  Buffers written per generation by A
     // and read by B (hit records, hit list) alternate between two copies; A reuses a copy once the lighting
     // of the generation before last has read it.
-    int first_ov = S.max_depth + 1;
-    // (brute force launches are short: the extra launches of the split would cost more than the overlap gives)
-    if (c->overlap_rays && c->accel == RT_ACCEL_LBVH && c->gen_rays_known && c->stream2 && c->alt_capacity >= cap && S.max_depth >= 1) {
-        while (first_ov > 0 && c->gen_rays[first_ov - 1] <= c->overlap_rays) first_ov--;
-        if (first_ov == S.max_depth && S.max_depth > 0) first_ov = S.max_depth + 1;     // a lone last generation has nothing to overlap with
-    }
-    const bool any_ov = first_ov <= S.max_depth;
-    if (c->reported_first_ov != first_ov && getenv("RT_VERBOSE")) {
-        if (any_ov) fprintf(stderr, "[rt overlap] generations %d..%d on two streams (expected rays there: %llu and fewer)\n", first_ov,
-                            S.max_depth, (unsigned long long)c->gen_rays[first_ov]);
-        else fprintf(stderr, "[rt overlap] none\n");
-        c->reported_first_ov = first_ov;
-    }
-    hipStream_t B = c->stream2;
-    StageTimes tmB;
-    tmB.st = B; tmB.on = tm.on && any_ov; tmB.pool = &c->event_pool; tmB.only = tm.only;
     for (int g = 0; g <= S.max_depth; g++) {
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
@@ -721,6 +723,89 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     if (c->count_work) rtk_reduce_stats(st, c->P, c->d_counters);
     LAUNCH_CHECK("resolve / finish", -1);
     tm.mark(3);
+    return RT_OK;
+}
+
+// Everything the launches of a batch take by value, as bytes: two batches with the same bytes queue the same launches.
+static void batch_key(const rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode, const void* d_out, const void* d_outf,
+                      int first_ov, std::vector<uint8_t>& key) {
+    key.clear();
+    auto put = [&key](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; key.insert(key.end(), b, b + n); };
+    const void* ptrs[] = {d_out, d_outf, c->d_tiles, c->d_counters, c->hp2, c->hn2, c->hd2, c->hitlist2, c->stream, c->stream2};
+    const int ints[] = {(int)tile0, (int)ntiles, shard_mode, first_ov, c->accel, c->max_blocks, c->inline_shadows ? 1 : 0,
+                        c->count_work ? 1 : 0, c->two_children ? 1 : 0};
+    put(ptrs, sizeof(ptrs)); put(ints, sizeof(ints));
+    put(c->mode_extend, sizeof(c->mode_extend)); put(c->mode_shadow, sizeof(c->mode_shadow));
+    put(&c->S, sizeof(DScene)); put(&c->P, sizeof(DPool)); put(&c->cam, sizeof(DCamera));
+}
+
+// Enqueues one batch (tiles [tile0, tile0+ntiles) of the current partition) and
+// waits for it.  All launches are asynchronous; the only host sync is the final
+// read of the counters (overflow flag + ray statistics).
+static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode, uint8_t* d_out, float* d_outf,
+                     BatchResult& res, StageTimes& tm) {
+    const DScene& S = c->S;
+    const uint32_t spp = (uint32_t)c->cam.spp;
+    const uint32_t npixels = ntiles * RT_TILE_AREA;
+    const uint64_t nsamples64 = (uint64_t)npixels * spp;
+    hipStream_t st = c->stream;
+    const uint64_t cap = c->P.capacity;
+    const auto host_t0 = std::chrono::steady_clock::now();
+    int first_ov = S.max_depth + 1;
+    // (brute force launches are short: the extra launches of the split would cost more than the overlap gives)
+    if (c->overlap_rays && c->accel == RT_ACCEL_LBVH && c->gen_rays_known && c->stream2 && c->alt_capacity >= cap && S.max_depth >= 1) {
+        while (first_ov > 0 && c->gen_rays[first_ov - 1] <= c->overlap_rays) first_ov--;
+        if (first_ov == S.max_depth && S.max_depth > 0) first_ov = S.max_depth + 1;     // a lone last generation has nothing to overlap with
+    }
+    const bool any_ov = first_ov <= S.max_depth;
+    if (c->reported_first_ov != first_ov && getenv("RT_VERBOSE")) {
+        if (any_ov) fprintf(stderr, "[rt overlap] generations %d..%d on two streams (expected rays there: %llu and fewer)\n", first_ov,
+                            S.max_depth, (unsigned long long)c->gen_rays[first_ov]);
+        else fprintf(stderr, "[rt overlap] none\n");
+        c->reported_first_ov = first_ov;
+    }
+    StageTimes tmB;
+    tmB.st = c->stream2; tmB.on = tm.on && any_ov; tmB.pool = &c->event_pool; tmB.only = tm.only;
+    // Thin batches run as a graph from the second time the same launches come (see rt_ctx::graphs).  Not while stage
+    // times are taken (events recorded under capture carry no time stamps) nor with the tuning aids on.
+    rt_ctx::BatchGraph* bg = nullptr;
+    if (c->graphs_on && !tm.on && !S.profile && nsamples64 <= c->graph_max_samples) {
+        std::vector<uint8_t> key;
+        batch_key(c, tile0, ntiles, shard_mode, d_out, d_outf, first_ov, key);
+        for (auto& g : c->graphs)
+            if (g.key == key) { bg = &g; break; }
+        if (!bg) {
+            if (c->graphs.size() >= 16) drop_graphs(c);       // (nothing of this context is in flight between batches)
+            c->graphs.emplace_back();
+            bg = &c->graphs.back();
+            bg->key.swap(key);
+        }
+        bg->seen++;
+    }
+    bool queued = false;
+    if (bg && bg->exec) {
+        if (first_ov > 0) c->shade_shadowed = c->accel == RT_ACCEL_BRUTE && c->inline_shadows && !c->count_work && !S.profile;
+        HIP_TRY(hipGraphLaunch(bg->exec, st));
+        c->graph_replays++;
+        queued = true;
+    } else if (bg && bg->seen >= 2 && !bg->failed) {
+        // capture this batch's launches (both streams: the second joins through the events) instead of running them
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = enqueue_batch(c, tile0, ntiles, shard_mode, d_out, d_outf, first_ov, tm, tmB);
+            const hipError_t ee = hipStreamEndCapture(st, &graph);
+            if (rc == RT_OK && ee == hipSuccess && graph && hipGraphInstantiate(&bg->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                if (hipGraphLaunch(bg->exec, st) == hipSuccess) { c->graph_replays++; queued = true; }
+                else { hipGraphExecDestroy(bg->exec); bg->exec = nullptr; }
+            }
+            if (graph) hipGraphDestroy(graph);
+        }
+        if (!queued) { (void)hipGetLastError(); bg->failed = true; bg->exec = nullptr; }    // queue it directly, now and from now on
+    }
+    if (!queued) {
+        const int rc = enqueue_batch(c, tile0, ntiles, shard_mode, d_out, d_outf, first_ov, tm, tmB);
+        if (rc != RT_OK) return rc;
+    }
     DCounters hc;
     res.host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
@@ -1340,6 +1425,20 @@ extern "C" int rt_set_progress_callback(rt_ctx* c, rt_progress_fn fn, void* user
 extern "C" int rt_set_stage_times(rt_ctx* c, int on) {
     if (!c) return RT_ERR_INVALID;
     c->stage_times = (on == 2 || on == 3) ? on : (on != 0 ? 1 : 0);
+    return RT_OK;
+}
+
+extern "C" int rt_set_graphs(rt_ctx* c, int on, uint64_t* replays) {
+    if (!c) return RT_ERR_INVALID;
+    if (on >= 0) {
+        c->graphs_on = on != 0;
+        if (!c->graphs_on) {
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            drop_graphs(c);
+        }
+    }
+    if (replays) *replays = c->graph_replays;
     return RT_OK;
 }
 

@@ -424,6 +424,49 @@ def test_calibration_is_optional_and_does_not_change_the_image(name, kw):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
 
 
+@pytest.mark.parametrize("name,kw,accel", [("spheres1", dict(width=640, height=480, spp=1), ra.RT_ACCEL_BRUTE),
+                                            ("spheres2", dict(width=320, height=240, spp=2), ra.RT_ACCEL_LBVH),
+                                            ("dragon", dict(width=320, height=200, spp=2), ra.RT_ACCEL_LBVH),
+                                            ("plant_h_smooth", dict(width=330, height=256, spp=1, max_depth=8), ra.RT_ACCEL_LBVH)])
+def test_batches_replayed_as_graphs_render_the_same_image(name, kw, accel):
+    """rt_set_graphs: a thin batch is captured the second time its launches come and replayed from then on (both
+    streams of the overlapped generations inside the graph); frames, float frames and ray counts equal those of the
+    directly queued launches, also after a change of film (new launches, new graph) and back."""
+    scene = load_scene(name).copy(**kw)
+    other = scene.copy(width=kw["width"] // 2, height=kw["height"] // 2)
+    with ra.Tracer(accel=accel) as t:
+        t.set_graphs(False)
+        t.load_scene(scene)
+        rgb0, f0, st0 = t.render(want_float=True)
+        t.load_scene(other)
+        rgb1, f1, st1 = t.render(want_float=True)
+        assert t.set_graphs() == 0
+    with ra.Tracer(accel=accel) as t:
+        t.load_scene(scene)
+        for i in range(5):
+            rgb, f, st = t.render(want_float=True)
+            assert np.array_equal(rgb, rgb0) and np.array_equal(bits(f), bits(f0)) and st.rays == st0.rays, i
+        n = t.set_graphs()
+        assert n >= 2, "no batch ran as a graph launch"
+        t.load_scene(other)
+        for i in range(4):
+            rgb, f, st = t.render(want_float=True)
+            assert np.array_equal(rgb, rgb1) and np.array_equal(bits(f), bits(f1)) and st.rays == st1.rays, i
+        assert t.set_graphs() > n
+        t.load_scene(scene)
+        for i in range(3):
+            rgb, f, st = t.render(want_float=True)
+            assert np.array_equal(rgb, rgb0) and np.array_equal(bits(f), bits(f0)) and st.rays == st0.rays, i
+        # a frame with stage times is queued directly, and the graph is still good afterwards
+        n = t.set_graphs()
+        t.set_stage_times(1)
+        rgb, f, st = t.render(want_float=True)
+        assert np.array_equal(rgb, rgb0) and t.set_graphs() == n
+        t.set_stage_times(0)
+        rgb, f, st = t.render(want_float=True)
+        assert np.array_equal(rgb, rgb0) and np.array_equal(bits(f), bits(f0))
+
+
 def test_work_counters_are_optional_and_do_not_change_the_image(tracer):
     scene = load_scene("dragon").copy(width=128, height=96, spp=2)
     tracer.load_scene(scene)
