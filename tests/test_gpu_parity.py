@@ -721,6 +721,31 @@ def test_repeated_frames_are_byte_identical(tracer, name, kw):
         assert bool((first == again).all())
 
 
+def test_host_buffer_render_equals_the_frame_in_device_memory(monkeypatch):
+    """rt_render brings a frame of 8 MiB and more to the caller's buffer through pinned staging chunks and host threads,
+    a smaller one (or RT_FAST_COPY=0) by one plain copy: the bytes are those rt_render_device leaves in device memory,
+    for the 8-bit and the float frame, also when a small frame follows a large one on the same context."""
+    import torch
+    big = load_scene("spheres1").copy(width=2048, height=1500, spp=1)          # 9.2 MB of RGB8, 36.9 MB of floats
+    small = big.copy(width=640, height=480)
+    frames = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("RT_FAST_COPY", fast)
+        with ra.Tracer(accel=ra.RT_ACCEL_BRUTE) as t:
+            for scene in (big, small, big):
+                t.load_scene(scene)
+                rgb, f, st = t.render(want_float=True)
+                dev = torch.zeros((scene.height, scene.width, 3), dtype=torch.uint8, device="cuda:0")
+                t.render_device(dev.data_ptr())
+                assert np.array_equal(rgb, dev.cpu().numpy()), (fast, scene.width)
+                rgb2, _, _ = t.render()
+                assert np.array_equal(rgb, rgb2)
+                key = (scene.width, scene.height)
+                if key in frames:
+                    assert np.array_equal(frames[key][0], rgb) and np.array_equal(bits(frames[key][1]), bits(f)), (fast, key)
+                frames[key] = (rgb, f)
+
+
 def test_render_on_a_caller_provided_stream(tracer):
     """rt_options.stream: every launch of the context goes to the caller's HIP stream (here a torch stream),
     so work the caller queued on it before the call is seen by the render, and the result is the same image."""

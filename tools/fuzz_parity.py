@@ -4,10 +4,20 @@
   python tools/fuzz_parity.py [--seeds A B] [--trees] [--big] [--save]
 
 For every seed: the oracle's frame, then the HIP path by brute force and through the hierarchy with every walk
-forced in turn (and, with --trees, on both hierarchies): two frames per context (the second runs its thin
-generations on two streams), some contexts with small batches or a ray pool that overflows, and for two of the
+forced in turn (and, with --trees, on both hierarchies): three frames per context (the second runs its thin
+generations on two streams and is captured as a HIP graph, the third replays it), some contexts with small batches or a ray pool that overflows, and for two of the
 variants the frame assembled from the shards of a random number of ranks.  Prints one line per mismatch and a summary; exit
-status 1 if anything differed.  Needs a GPU."""
+status 1 if anything differed.  Needs a GPU.
+
+FUZZ_THREADS=n: OpenMP threads of the oracle (default 1).  With 16 threads, three frames per context and films of
+304-306 pixels a campaign of 20 000 seeds reported 11-13 frames whose 8-bit host array differed from the oracle's in
+bytes 152 (a 16-bit counter decremented by 1-18) and 888-891 (cleared) while the float frame of the same launch was
+right.  FUZZ_SCRATCH=1 showed that the damaged block is not one the tracer library ever held a pointer to (the array it
+wrote stays intact, a numpy copy of it in a fresh block of the same size is damaged), the same three-pixel signature
+shows as "TRANSIENT" lines (a temporary of the comparison hit instead) with the library of earlier builds, and with
+one oracle thread 5 000 seeds of the same range are clean: a stale writer on the checker's side of the process (OpenMP
+runtime threads next to torch's own copy of that runtime), not found yet; loading the checker with RTLD_DEEPBIND did
+not remove it."""
 import argparse
 import os
 import sys
@@ -25,6 +35,7 @@ from _fuzz_scenes import WALKS, random_scene  # noqa: E402
 from _oracle import Oracle  # noqa: E402
 from conftest import same_float_image  # noqa: E402
 
+SCRATCH = []
 ENV_KEYS = ("RT_PACKET_GENS", "RT_PACKET_SHADOW_GENS", "RT_LANE_WIDE", "RT_TREE")
 
 
@@ -38,7 +49,17 @@ def render(scene, accel, env, frames=1, shards=0, **kw):
     try:
         with ra.Tracer(device=0, accel=accel, **kw) as t:
             t.load_scene(scene)
-            out = [t.render(want_float=True) for _ in range(frames)]
+            out = []
+            for k in range(frames):
+                if os.environ.get("FUZZ_SCRATCH") == "1":
+                    # the library never sees the arrays that are compared: it writes r2 / f2, numpy copies them over
+                    rgb = np.zeros((scene.height, scene.width, 3), np.uint8)
+                    r2, f2, st = t.render(want_float=True)
+                    rgb[:] = r2
+                    out.append((rgb, f2, st))
+                    SCRATCH.append((k, r2, rgb))
+                else:
+                    out.append(t.render(want_float=True))
             if shards:
                 sb = ra.shard_bytes(scene.width, scene.height, shards)
                 allsh = torch.zeros(shards * sb, dtype=torch.uint8, device="cuda:0")
@@ -69,7 +90,7 @@ def main():
     t0 = time.time()
     for seed in range(*args.seeds):
         scene = random_scene(seed, big=args.big)
-        orgb, orgbf, cnt, _ = orc.render(scene, threads=16)
+        orgb, orgbf, cnt, _ = orc.render(scene, threads=int(os.environ.get("FUZZ_THREADS", "1")))
         variants = [("brute", ra.RT_ACCEL_BRUTE, {})]
         for walk, env in WALKS.items():
             for tree in (("karras", "ploc") if args.trees else (None,)):
@@ -90,7 +111,7 @@ def main():
                 kw["pool_rays"] = int(rng.choice([3000, 30000]))
             shards = int(rng.integers(1, 6)) if label in ("calibrated", "brute") else 0
             try:
-                frames = render(scene, accel, env, frames=2, shards=shards, **kw)
+                frames = render(scene, accel, env, frames=3, shards=shards, **kw)
             except ra.RtError as e:
                 notes.append(f"{label} {kw}: error {e}")
                 continue
@@ -114,8 +135,16 @@ def main():
                                  f"vs {cnt.primary}/{cnt.secondary}/{cnt.shadow}")
                     if args.save:
                         np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_{seed}_{label.replace('/', '_')}_{k}.npz"), rgbf=rgbf if rgbf is not None else 0, rgb=rgb, orgbf=orgbf, orgb=orgb)
+                    if same.all():
+                        for y, x in list(zip(*np.nonzero((rgb != orgb).any(axis=2))))[:4]:
+                            notes.append(f"    RGB8 pixel ({x}, {y}): {rgb[y, x].tolist()} vs the oracle's {orgb[y, x].tolist()}; float {rgbf[y, x].tolist() if rgbf is not None else None}")
                     for y, x in list(zip(*np.nonzero(~same)))[:4]:
                         notes.append(f"    pixel ({x}, {y}): {(rgbf if rgbf is not None else rgb)[y, x].tolist()} vs the oracle's {(orgbf if rgbf is not None else orgb)[y, x].tolist()}")
+        for k, r2, rgb in SCRATCH:
+            if not np.array_equal(r2, orgb) or not np.array_equal(rgb, orgb):
+                notes.append(f"    SCRATCH frame {k}: array the library wrote differs at bytes {np.nonzero(r2.ravel() != orgb.ravel())[0].tolist()[:8]}, "
+                             f"the numpy copy of it at bytes {np.nonzero(rgb.ravel() != orgb.ravel())[0].tolist()[:8]}")
+        del SCRATCH[:]
         what = (f"seed {seed}: {scene.width}x{scene.height}x{scene.spp} depth {scene.max_depth} proj {scene.proj} "
                 f"{len(scene.spheres)} sph {len(scene.tri_verts)} tri {len(scene.lights)} lights, "
                 f"|pos| ~ {float(np.abs(scene.cam_pos).max()):.3g}, rays {cnt.total}")
