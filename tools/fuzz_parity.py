@@ -14,10 +14,10 @@ FUZZ_THREADS=n: OpenMP threads of the oracle (default 1).  With 16 threads, thre
 bytes 152 (a 16-bit counter decremented by 1-18) and 888-891 (cleared) while the float frame of the same launch was
 right.  FUZZ_SCRATCH=1 showed that the damaged block is not one the tracer library ever held a pointer to (the array it
 wrote stays intact, a numpy copy of it in a fresh block of the same size is damaged), the same three-pixel signature
-shows as "TRANSIENT" lines (a temporary of the comparison hit instead) with the library of earlier builds, and with
-one oracle thread 5 000 seeds of the same range are clean: a stale writer on the checker's side of the process (OpenMP
-runtime threads next to torch's own copy of that runtime), not found yet; loading the checker with RTLD_DEEPBIND did
-not remove it."""
+shows as "TRANSIENT" lines (a temporary of the comparison hit instead) with the library of earlier builds.  5 000 seeds
+of the same range are clean with one oracle thread, with 16 threads that sleep instead of spinning
+(OMP_WAIT_POLICY=passive GOMP_SPINCOUNT=0), and with 16 spinning threads when nothing calls the tracer library or the
+HIP runtime: a use-after-free race on the GPU side of the process that CPU contention exposes, not found yet."""
 import argparse
 import os
 import sys
