@@ -17,7 +17,8 @@ wrote stays intact, a numpy copy of it in a fresh block of the same size is dama
 shows as "TRANSIENT" lines (a temporary of the comparison hit instead) with the library of earlier builds.  5 000 seeds
 of the same range are clean with one oracle thread, with 16 threads that sleep instead of spinning
 (OMP_WAIT_POLICY=passive GOMP_SPINCOUNT=0), and with 16 spinning threads when nothing calls the tracer library or the
-HIP runtime: a use-after-free race on the GPU side of the process that CPU contention exposes, not found yet."""
+HIP runtime, and with RT_OVERLAP_RAYS=0 (no second stream, no events crossing streams): a use-after-free race around
+the cross-stream events that CPU contention exposes, not found yet."""
 import argparse
 import os
 import sys
