@@ -59,6 +59,7 @@ extern "C" const char* rt_strerror(int status) {
 static __device__ __align__(256) uint32_t scratch[RT_NOALLOC_MAX_ROWS];
 
 #define RT_MAX_DEVICES 64
+
 static std::mutex g_scratch_mutex;
 static uint32_t* g_scratch_ptr[RT_MAX_DEVICES];      // per device ordinal; nullptr = not looked up yet
 
@@ -78,6 +79,55 @@ static int scratch_on_device(int device, uint32_t** out) {
     }
     *out = g_scratch_ptr[device];
     return RT_OK;
+}
+
+// ---------------------------------------------------------------- streams
+// Streams this library creates are never destroyed: a context returns them to a per-device list and the next
+// context takes them from there.  Reason: the HIP runtime registers completion handlers for the marker commands of a
+// stream (event records, waits on events of other streams, synchronisations), run later by a thread of the HSA
+// runtime.  In the runtime of ROCm 7.0 (the libamdhip64.so that PyTorch 2.10+rocm7.0 bundles, which a process
+// that imports torch first runs on) such a handler holds a plain pointer to the stream's queue object, and
+// hipStreamDestroy frees that object without waiting for handlers still pending: a handler that runs late -- the
+// handler thread gets no CPU while other threads of the process spin -- then decrements a counter and clears a word
+// in memory that has been handed out again.  (The runtime of ROCm 7.2 holds a reference on the queue object for
+// every pending handler.)  A stream that lives as long as the process has no such window.
+static std::mutex g_stream_mutex;
+static std::vector<hipStream_t> g_spare_streams[RT_MAX_DEVICES];
+
+// A non-blocking stream on `device` (which must be the current device of the calling thread).
+static hipError_t acquire_stream(int device, hipStream_t* out) {
+    *out = nullptr;
+    if (device >= 0 && device < RT_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        if (!g_spare_streams[device].empty()) {
+            *out = g_spare_streams[device].back();
+            g_spare_streams[device].pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+// Gives a stream of acquire_stream back, idle (the caller has synchronised it).
+static void recycle_stream(int device, hipStream_t s) {
+    if (!s) return;
+    if (device >= 0 && device < RT_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        g_spare_streams[device].push_back(s);
+    }
+    // (a device ordinal beyond the table: the stream is left alone rather than destroyed)
+}
+
+// Graphs with parallel branches run their side branches on streams the runtime creates with the executable graph and
+// destroys with it: the same window.  Such graphs are only used on runtimes that keep the queue object alive for
+// pending handlers (ROCm 7.2 on: HIP_VERSION 7.2).
+static bool runtime_keeps_queues_alive() {
+    static const bool ok = [] {
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return v >= 70200000;
+    }();
+    return ok;
 }
 
 // ---------------------------------------------------------------- context
@@ -235,7 +285,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->max_blocks = c->num_cu * 8;
     if (c->opt.stream) { c->stream = (hipStream_t)c->opt.stream; c->own_stream = false; }
-    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    else { HIP_TRY(acquire_stream(c->device, &c->stream)); c->own_stream = true; }
     HIP_TRY(hipMalloc(&c->d_counters, sizeof(DCounters)));
     HIP_TRY(hipHostMalloc((void**)&c->h_counters, sizeof(DCounters), hipHostMallocDefault));
     {
@@ -252,6 +302,8 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
 extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    // both streams idle before anything they may still use goes away
+    if (c->stream2) hipStreamSynchronize(c->stream2);
     if (c->stream) hipStreamSynchronize(c->stream);
     drop_graphs(c);
     free_scene(c);
@@ -259,15 +311,17 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (c->h_counters) hipHostFree(c->h_counters);
     hipFree(c->d_counters); hipFree(c->d_tiles); hipFree(c->d_rowbase); hipFree(c->d_rgb); hipFree(c->d_rgbf);
     hipFree(c->d_shard); hipFree(c->d_all);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    // the streams go back to the process-wide list (see acquire_stream: they are never destroyed); events last
+    recycle_stream(c->device, c->stream2);
+    if (c->own_stream) recycle_stream(c->device, c->stream);
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (auto e : c->ev_scan) hipEventDestroy(e);
     for (auto e : c->ev_light) hipEventDestroy(e);
     for (auto e : c->copy_events) hipEventDestroy(e);
-    if (c->h_stage) hipHostFree(c->h_stage);
-    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    (void)hipGetLastError();
     delete c;
 }
 
@@ -612,24 +666,10 @@ struct StageTimes {
     }
 };
 
-// A launch that the runtime rejects (bad configuration, missing code object) is reported by the next
-// hipGetLastError, not by the launch: ask after every launch group and name the stage, so a failure does
-// not surface as an anonymous error at the final synchronisation.
-#define LAUNCH_CHECK(stage, g)                                                                        \
-    do {                                                                                              \
-        hipError_t e_ = hipGetLastError();                                                            \
-        if (e_ != hipSuccess) {                                                                       \
-            char b_[200];                                                                             \
-            std::snprintf(b_, sizeof(b_), "launch of %s (generation %d): %s", stage, g, hipGetErrorString(e_)); \
-            rt_set_error(b_);                                                                         \
-            return RT_ERR_HIP;                                                                        \
-        }                                                                                             \
-    } while (0)
-
 // What the overlapped pipeline needs beyond the pool: a second stream, one event pair per generation and
 // the second copy of the per-generation buffers.
 static int ensure_overlap(rt_ctx* c) {
-    if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!c->stream2) HIP_TRY(acquire_stream(c->device, &c->stream2));
     while (c->ev_scan.size() < (size_t)RT_MAX_GEN + 1) {
         hipEvent_t a, b;
         HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -651,6 +691,8 @@ static int ensure_overlap(rt_ctx* c) {
 }
 
 // Queues the launches of one batch on the context's streams (or, while stream A is being captured, into the graph).
+// On an error nothing is left split: work already queued on the second stream is joined back into the first, so that
+// the caller can wait for the first stream alone and a capture in progress can end.
 static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode, uint8_t* d_out, float* d_outf,
                          int first_ov, StageTimes& tm, StageTimes& tmB) {
     const DScene& S = c->S;
@@ -660,11 +702,25 @@ static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_m
     hipStream_t B = c->stream2;
     const uint64_t cap = c->P.capacity;
     const bool any_ov = first_ov <= S.max_depth;
+    int rc = RT_OK;
+    int last_b = -1;               // last generation whose second-stream work was queued (-1: none yet)
+    // A launch that the runtime rejects (bad configuration, missing code object) is reported by the next
+    // hipGetLastError, not by the launch: ask after every launch group and name the stage, so a failure does
+    // not surface as an anonymous error at the final synchronisation.
+    auto failed = [&](const char* stage, int g) {
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) return false;
+        char b[200];
+        std::snprintf(b, sizeof(b), "launch of %s (generation %d): %s", stage, g, hipGetErrorString(e));
+        rt_set_error(b);
+        rc = RT_ERR_HIP;
+        return true;
+    };
     tm.mark(3);
     rtk_init_counters(st, c->d_counters, nsamples, c->P, S.max_depth + 1, c->count_work || S.profile);
     tm.mark(3);
     if (S.max_depth < 0) rtk_fill_background(st, S, c->P, nsamples, c->max_blocks);   // nothing is traced at all
-    LAUNCH_CHECK("init", -1);
+    if (failed("init", -1)) return rc;
     uint64_t bound = nsamples;
     // The generations of the batch.  Fat ones run one after the other on the context's stream (A): extend ->
     // scan -> shadow -> shade.  From the first generation expected to be thin on (few rays: launches that last
@@ -675,7 +731,7 @@ static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_m
     // hits) runs on B, in generation order, after the lighting of g - 1.  Buffers written per generation by A
     // and read by B (hit records, hit list) alternate between two copies; A reuses a copy once the lighting
     // of the generation before last has read it.
-    for (int g = 0; g <= S.max_depth; g++) {
+    for (int g = 0; g <= S.max_depth && rc == RT_OK; g++) {
         // LBVH: generations whose rays are still coherent walk the tree as wave packets
         int acc_e = c->accel, acc_s = c->accel;
         if (c->accel == RT_ACCEL_LBVH) { acc_e = c->mode_extend[g]; acc_s = c->mode_shadow[g]; }
@@ -687,10 +743,10 @@ static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_m
         if (ov && g - 2 >= first_ov) { hipStreamWaitEvent(st, c->ev_light[g - 2], 0); tm.mark(-1); }
         tm.begin(0);
         rtk_extend(st, acc_e, S, P, c->d_counters, c->cam, c->d_tiles, tile0, g, bound, c->max_blocks, c->count_work, c->launch_cache, ov);
-        LAUNCH_CHECK("extend", g);
+        if (failed("extend", g)) break;
         tm.mark(0);
         rtk_compact(st, P, c->d_counters, g, bound, c->max_blocks, acc_e);
-        LAUNCH_CHECK("compact", g);
+        if (failed("compact", g)) break;
         tm.mark(3);
         const uint64_t items = bound * (uint64_t)std::max(1, S.nl);
         if (!ov) {
@@ -701,11 +757,11 @@ static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_m
             if (!shade_shadows) {
                 tm.begin(1);
                 rtk_shadow(st, acc_s, S, P, c->d_counters, g, items, c->max_blocks, c->count_work, c->launch_cache);
-                LAUNCH_CHECK("shadow", g);
+                if (failed("shadow", g)) break;
                 tm.mark(1);
             }
             rtk_shade(st, S, P, c->d_counters, g, bound, c->max_blocks, shade_shadows ? 3 : 0);
-            LAUNCH_CHECK("shade", g);
+            if (failed("shade", g)) break;
             tm.mark(2);
         } else {
             hipEventRecord(c->ev_scan[g], st);
@@ -714,6 +770,7 @@ static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_m
                 tm.mark(2);
             }
             hipStreamWaitEvent(B, c->ev_scan[g], 0);
+            last_b = g;
             tmB.mark(-1);
             if (g >= 1) rtk_miss(B, S, P, c->d_counters, g, bound, c->max_blocks);
             tmB.mark(3);
@@ -723,16 +780,26 @@ static int enqueue_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_m
             rtk_shade(B, S, P, c->d_counters, g, bound, c->max_blocks, 2);
             tmB.mark(2);
             hipEventRecord(c->ev_light[g], B);
-            LAUNCH_CHECK("spawn / miss / shadow / light (two streams)", g);
+            if (failed("spawn / miss / shadow / light (two streams)", g)) break;
         }
         bound = std::min<uint64_t>(bound * 2, cap);
+    }
+    if (rc != RT_OK) {
+        // join: everything queued on B so far precedes whatever follows on A (the record of this generation may be
+        // the very call that failed, so a fresh one is made)
+        if (last_b >= 0) {
+            hipEventRecord(c->ev_light[last_b], B);
+            hipStreamWaitEvent(st, c->ev_light[last_b], 0);
+            (void)hipGetLastError();
+        }
+        return rc;
     }
     if (any_ov) { hipStreamWaitEvent(st, c->ev_light[S.max_depth], 0); tm.mark(-1); }
     for (int g = S.max_depth - 1; g >= 0 && c->two_children; g--)
         rtk_resolve(st, S, c->P, c->d_counters, g, std::min<uint64_t>((uint64_t)nsamples << std::min(g, 20), cap), c->max_blocks);
     rtk_finish(st, c->cam, c->P, c->d_tiles, tile0, npixels, shard_mode, d_out, d_outf, c->max_blocks);
     if (c->count_work) rtk_reduce_stats(st, c->P, c->d_counters);
-    LAUNCH_CHECK("resolve / finish", -1);
+    if (failed("resolve / finish", -1)) return rc;
     tm.mark(3);
     return RT_OK;
 }
@@ -779,8 +846,11 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     tmB.st = c->stream2; tmB.on = tm.on && any_ov; tmB.pool = &c->event_pool; tmB.only = tm.only;
     // Thin batches run as a graph from the second time the same launches come (see rt_ctx::graphs).  Not while stage
     // times are taken (events recorded under capture carry no time stamps) nor with the tuning aids on.
+    // A batch split over two streams becomes a graph with two branches, whose second branch the runtime runs on a
+    // stream of its own that is destroyed with the executable graph: only on runtimes where that is safe (see
+    // runtime_keeps_queues_alive); elsewhere such batches are queued launch by launch.
     rt_ctx::BatchGraph* bg = nullptr;
-    if (c->graphs_on && !tm.on && !S.profile && nsamples64 <= c->graph_max_samples) {
+    if (c->graphs_on && !tm.on && !S.profile && nsamples64 <= c->graph_max_samples && (!any_ov || runtime_keeps_queues_alive())) {
         std::vector<uint8_t> key;
         batch_key(c, tile0, ntiles, shard_mode, d_out, d_outf, first_ov, key);
         for (auto& g : c->graphs)
@@ -815,7 +885,15 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     }
     if (!queued) {
         const int rc = enqueue_batch(c, tile0, ntiles, shard_mode, d_out, d_outf, first_ov, tm, tmB);
-        if (rc != RT_OK) return rc;
+        if (rc != RT_OK) {
+            // nothing of the batch is in flight when the caller sees the error (it may free the buffers next)
+            const std::string why = rt_last_error();
+            hipStreamSynchronize(st);
+            if (c->stream2) hipStreamSynchronize(c->stream2);
+            (void)hipGetLastError();
+            rt_set_error(why);
+            return rc;
+        }
     }
     res.host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
@@ -1181,11 +1259,10 @@ extern "C" int rt_render_device(rt_ctx* c, void* d_rgb, rt_stats* stats) {
 }
 
 // Device-to-host copy of a finished frame into the caller's (pageable) buffer, queued on the context's stream and
-// complete on return.  The frame never goes to pageable memory through the runtime: a plain copy there is staged by
-// the runtime at about 8 GB/s (3 ms for the 25 MB of a 3840x2160 frame), and what the caller reads right after the
-// stream is synchronised has been seen to lag the copy by microseconds for small frames.  The frame goes to pinned
-// staging memory of the context -- 2 MiB chunks at the link's rate, an event after each -- and the calling thread
-// plus up to three helpers copy the chunks on as their events complete (one chunk: no events, no helpers).
+// complete on return.  A bandwidth choice: a plain copy into pageable memory is staged by the runtime at about 8 GB/s
+// (3 ms for the 25 MB of a 3840x2160 frame).  The frame goes to pinned staging memory of the context instead -- 2 MiB
+// chunks at the link's rate, an event after each -- and the calling thread plus up to three helpers copy the chunks
+// on as their events complete (one chunk: no events, no helpers).
 static int copy_out(rt_ctx* c, void* dst, const void* src, size_t bytes) {
     const size_t CH = (size_t)2 << 20;
     if (bytes == 0) return RT_OK;

@@ -3,8 +3,6 @@
 `tools/fuzz_parity.py` (the same loop over thousands of seeds) has found a difference: tiny spheres seen from
 far away, which the reference's float sphere test "hits" well outside their radius."""
 import os
-import time
-import warnings
 
 import numpy as np
 import pytest
@@ -20,18 +18,8 @@ FOUND = (79, 2989, 11138, 13308)          # seeds of earlier findings
 
 
 def _same(rgbf, orgbf, what):
-    """Per-pixel bit equality of two host arrays.  A difference is looked at twice: on these boxes a comparison made
-    right after a small device-to-host copy has (four times in half a million) reported pixels that a second
-    comparison of the same two arrays, microseconds later, found equal -- with this library's copy and with torch's
-    alike.  What the GPU computed is what the arrays hold once they stand still; a wrong pixel stays wrong."""
-    same = same_float_image(rgbf, orgbf).all(axis=2)
-    if not same.all():
-        time.sleep(0.01)
-        again = same_float_image(rgbf, orgbf).all(axis=2)
-        if again.all():
-            warnings.warn(f"{what}: {int((~same).sum())} pixels differed on the first read of the host arrays and none on the second")
-        same = again
-    return same
+    """Per-pixel bit equality of two host arrays, looked at ONCE: a first-read difference fails its test."""
+    return same_float_image(rgbf, orgbf).all(axis=2)
 
 
 def _render(monkeypatch, scene, accel, env, frames=1):
