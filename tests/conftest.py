@@ -71,3 +71,12 @@ def same_float_image(a, b):
     """bit equality, treating any NaN as equal to any NaN"""
     a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
     return (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+
+
+def hip_runtime_version():
+    """HIP_VERSION of the runtime this process runs on (torch's bundled one when torch was imported first)"""
+    import ctypes
+    v = ctypes.c_int(0)
+    rc = ctypes.CDLL("libamdhip64.so.7").hipRuntimeGetVersion(ctypes.byref(v))     # the copy already loaded, by soname
+    assert rc == 0
+    return v.value

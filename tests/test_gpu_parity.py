@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import raytracer_amd as ra
-from conftest import bits, golden_cases, load_case, load_scene, same_float_image
+from conftest import bits, golden_cases, hip_runtime_version, load_case, load_scene, same_float_image
 
 pytestmark = pytest.mark.gpu
 
@@ -431,7 +431,10 @@ def test_calibration_is_optional_and_does_not_change_the_image(name, kw):
 def test_batches_replayed_as_graphs_render_the_same_image(name, kw, accel):
     """rt_set_graphs: a thin batch is captured the second time its launches come and replayed from then on (both
     streams of the overlapped generations inside the graph); frames, float frames and ray counts equal those of the
-    directly queued launches, also after a change of film (new launches, new graph) and back."""
+    directly queued launches, also after a change of film (new launches, new graph) and back.  Batches that run on two
+    streams (hierarchy scenes from the second frame on) become graphs only on HIP runtimes from 7.2 on: an older
+    runtime frees the queue object of the graph's side stream under completion handlers that are still pending."""
+    replayed = accel == ra.RT_ACCEL_BRUTE or hip_runtime_version() >= 70200000
     scene = load_scene(name).copy(**kw)
     other = scene.copy(width=kw["width"] // 2, height=kw["height"] // 2)
     with ra.Tracer(accel=accel) as t:
@@ -447,12 +450,12 @@ def test_batches_replayed_as_graphs_render_the_same_image(name, kw, accel):
             rgb, f, st = t.render(want_float=True)
             assert np.array_equal(rgb, rgb0) and np.array_equal(bits(f), bits(f0)) and st.rays == st0.rays, i
         n = t.set_graphs()
-        assert n >= 2, "no batch ran as a graph launch"
+        assert (n >= 2) if replayed else (n == 0), "no batch ran as a graph launch"
         t.load_scene(other)
         for i in range(4):
             rgb, f, st = t.render(want_float=True)
             assert np.array_equal(rgb, rgb1) and np.array_equal(bits(f), bits(f1)) and st.rays == st1.rays, i
-        assert t.set_graphs() > n
+        assert (t.set_graphs() > n) if replayed else (t.set_graphs() == 0)
         t.load_scene(scene)
         for i in range(3):
             rgb, f, st = t.render(want_float=True)
