@@ -209,11 +209,14 @@ int rt_render_multi(rt_ctx* const* ctxs, int n, uint8_t* rgb_out, rt_stats* stat
  * harnesses that forbid hipMalloc): no counterpart in the reference.  Same arguments, same
  * result, but the tile-row table the kernel needs lives in a fixed array in device memory that the library
  * holds per GPU (64 KiB) and is rebuilt by a small kernel on every call, so the call performs no
- * hipMalloc / hipFree.  Limit: world * ceil(height / RT_TILE) <= RT_NOALLOC_MAX_ROWS, else
- * RT_ERR_UNSUPPORTED.  The work is queued on the context's stream; the call waits for it
- * unless that stream is being captured.  All contexts on one GPU share that GPU's array:
- * calls that overlap in time on one GPU race. */
-#define RT_NOALLOC_MAX_ROWS 16384
+ * hipMalloc / hipFree.  The array is cut into RT_NOALLOC_SLOTS slices; a context owns one slice of its GPU's array
+ * from rt_create to rt_destroy, so different contexts -- and graphs captured from them, replayed at the same time --
+ * never share table entries.  Limits: world * ceil(height / RT_TILE) <= RT_NOALLOC_MAX_ROWS, and the context must
+ * be one of the first RT_NOALLOC_SLOTS living on its GPU; else RT_ERR_UNSUPPORTED.  The work is queued on the
+ * context's stream; the call waits for it unless that stream is being captured.  Calls on ONE context are
+ * serialised by its owner as all calls are; two graphs captured from the same context must not run at once. */
+#define RT_NOALLOC_MAX_ROWS 2048
+#define RT_NOALLOC_SLOTS 8
 int rt_assemble_shards_noalloc(rt_ctx* ctx, const void* d_all, int world, void* d_rgb);
 
 /* -------------------------------------------------------- query utilities */

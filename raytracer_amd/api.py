@@ -403,7 +403,7 @@ class Tracer:
             raise RtError(rc, "rt_assemble_shards")
 
     def assemble_shards_noalloc(self, d_all: int, world: int, d_rgb: int) -> None:
-        """rt_assemble_shards without any allocation (fixed per-GPU table; world * tile rows <= 16384)."""
+        """rt_assemble_shards without any allocation (a slice of a fixed per-GPU table; world * tile rows <= 2048, at most 8 contexts per GPU hold a slice)."""
         rc = self._lib.rt_assemble_shards_noalloc(self._ctx, d_all, world, d_rgb)
         if rc != RT_OK:
             raise RtError(rc, "rt_assemble_shards_noalloc")

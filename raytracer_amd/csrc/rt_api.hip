@@ -52,20 +52,24 @@ extern "C" const char* rt_strerror(int status) {
 
 // ---------------------------------------------------------------- allocation-free scratch
 // The one buffer rt_assemble_shards_noalloc needs beyond its inputs and outputs: the tile-row table.  A
-// fixed array in device memory, one copy per GPU the library runs on (held until the process ends).  `scratch`
-// is only a host-side handle of the symbol: the array's address on a device comes from
+// fixed array in device memory, one copy per GPU the library runs on (held until the process ends), cut into
+// RT_NOALLOC_SLOTS slices of RT_NOALLOC_MAX_ROWS entries: every context holds one slice of its GPU's array from
+// rt_create to rt_destroy, so contexts (and graphs captured from different contexts) never share table entries.
+// `scratch` is only a host-side handle of the symbol: the array's address on a device comes from
 // hipGetSymbolAddress with that device current, is looked up once per device (rt_create) and is what every
 // kernel argument uses.
-static __device__ __align__(256) uint32_t scratch[RT_NOALLOC_MAX_ROWS];
+static __device__ __align__(256) uint32_t scratch[RT_NOALLOC_SLOTS * RT_NOALLOC_MAX_ROWS];
 
 #define RT_MAX_DEVICES 64
-
 static std::mutex g_scratch_mutex;
 static uint32_t* g_scratch_ptr[RT_MAX_DEVICES];      // per device ordinal; nullptr = not looked up yet
+static uint32_t g_scratch_used[RT_MAX_DEVICES];      // per device: bit k set = slice k belongs to a living context
 
-// Address of `scratch` on `device` (which must be the current device of the calling thread).
-static int scratch_on_device(int device, uint32_t** out) {
+// Address of `scratch` on `device` (which must be the current device of the calling thread) and a free slice of it
+// (*slot = -1 when every slice is taken: that context's allocation-free entry point then reports it).
+static int scratch_on_device(int device, uint32_t** out, int* slot) {
     *out = nullptr;
+    *slot = -1;
     if (device < 0 || device >= RT_MAX_DEVICES) { rt_set_error("device ordinal beyond the scratch table"); return RT_ERR_UNSUPPORTED; }
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
@@ -77,8 +81,16 @@ static int scratch_on_device(int device, uint32_t** out) {
         }
         g_scratch_ptr[device] = p;
     }
-    *out = g_scratch_ptr[device];
+    for (int k = 0; k < RT_NOALLOC_SLOTS; k++)
+        if (!(g_scratch_used[device] & (1u << k))) { g_scratch_used[device] |= 1u << k; *slot = k; break; }
+    *out = g_scratch_ptr[device] + (size_t)std::max(0, *slot) * RT_NOALLOC_MAX_ROWS;
     return RT_OK;
+}
+
+static void scratch_release(int device, int slot) {
+    if (device < 0 || device >= RT_MAX_DEVICES || slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    g_scratch_used[device] &= ~(1u << slot);
 }
 
 // ---------------------------------------------------------------- streams
@@ -196,7 +208,8 @@ struct rt_ctx {
     std::vector<uint32_t> tiles;
     uint32_t* d_tiles = nullptr;
     uint32_t* d_rowbase = nullptr; int rowbase_world = -1, rowbase_w = -1, rowbase_h = -1;
-    uint32_t* scratch = nullptr;    // this device's copy of the allocation-free scratch array (shared by all its contexts)
+    uint32_t* scratch = nullptr;    // this context's slice of its device's allocation-free scratch array
+    int scratch_slot = -1;          // which slice (-1: all were taken when the context was created)
 
     // staging
     uint8_t* d_rgb = nullptr; float* d_rgbf = nullptr; size_t rgb_pixels = 0; size_t rgbf_pixels = 0;
@@ -289,7 +302,7 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     HIP_TRY(hipMalloc(&c->d_counters, sizeof(DCounters)));
     HIP_TRY(hipHostMalloc((void**)&c->h_counters, sizeof(DCounters), hipHostMallocDefault));
     {
-        int src = scratch_on_device(c->device, &c->scratch);     // the device is current here
+        int src = scratch_on_device(c->device, &c->scratch, &c->scratch_slot);     // the device is current here
         if (src != RT_OK) return src;
     }
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -315,6 +328,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     // the streams go back to the process-wide list (see acquire_stream: they are never destroyed); events last
     recycle_stream(c->device, c->stream2);
     if (c->own_stream) recycle_stream(c->device, c->stream);
+    scratch_release(c->device, c->scratch_slot);
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (auto e : c->ev_scan) hipEventDestroy(e);
     for (auto e : c->ev_light) hipEventDestroy(e);
@@ -1370,9 +1384,9 @@ extern "C" int rt_assemble_shards(rt_ctx* c, const void* d_all, int world, void*
     return RT_OK;
 }
 
-// The same de-interleave without any allocation: the table is rebuilt in this GPU's scratch array by a kernel
-// (every entry the assemble kernel reads is rewritten, so nothing of an earlier call survives), then the
-// assemble kernel reads it from there.  No hipMalloc / hipFree / host-to-device copy.
+// The same de-interleave without any allocation: the table is rebuilt in this context's slice of the GPU's scratch
+// array by a kernel (every entry the assemble kernel reads is rewritten, so nothing of an earlier call survives),
+// then the assemble kernel reads it from there.  No hipMalloc / hipFree / host-to-device copy.
 extern "C" int rt_assemble_shards_noalloc(rt_ctx* c, const void* d_all, int world, void* d_rgb) {
     if (!c || !d_all || !d_rgb || world <= 0) return RT_ERR_INVALID;
     if (!c->has_scene) return RT_ERR_NO_SCENE;
@@ -1386,6 +1400,10 @@ extern "C" int rt_assemble_shards_noalloc(rt_ctx* c, const void* d_all, int worl
         return RT_ERR_UNSUPPORTED;
     }
     if (!c->scratch) { rt_set_error("scratch array was not resolved on this device"); return RT_ERR_HIP; }
+    if (c->scratch_slot < 0) {
+        rt_set_error("rt_assemble_shards_noalloc: all slices of this GPU's fixed table were held by other contexts when this one was created");
+        return RT_ERR_UNSUPPORTED;
+    }
     HIP_TRY(hipSetDevice(c->device));
     rtk_rowbase(c->stream, world, ntx, nty, c->scratch);
     rtk_assemble(c->stream, (const uint8_t*)d_all, rt_shard_bytes(w, h, world), world, w, h, ntx, nty, c->scratch, (uint8_t*)d_rgb);
