@@ -42,3 +42,10 @@ def test_bench_reports_a_failing_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--film", "64", "64"], env=_env(RT_BENCH_STUB_FAIL_RANK="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_bench_does_not_start_ranks_from_under_a_profiler():
+    # rocprofv3's tool library has initialised the GPU before main() runs: no child processes from there
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=_env(ROCPROF_OUTPUT_PATH="x"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "rocprofv3" in r.stderr
