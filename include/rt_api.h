@@ -49,7 +49,9 @@ enum { RT_ACCEL_AUTO = 0, RT_ACCEL_BRUTE = 1, RT_ACCEL_LBVH = 2,
        RT_ACCEL_LBVH_TEAM = 5   /* rt_query_rays only: force the walk of the 4-wide collapse by a team of lanes per ray */,
        RT_ACCEL_ALT_TREE = 16   /* rt_query_rays only, OR-ed to an LBVH walk: use the second
                                    hierarchy (PLOC) that rt_load_scene built beside the Karras
-                                   one; available until the first render has chosen between them */ };
+                                   one; available until the first render has chosen between them */,
+       RT_ACCEL_SAH_TREE = 32   /* the same for the third hierarchy (binned surface-area build), where
+                                   rt_load_scene built it */ };
 
 /* One light: the fields of the reference's class Light (src/parse.h:188-195). */
 typedef struct rt_light {
@@ -237,6 +239,20 @@ int rt_query_rays(rt_ctx* ctx, int64_t n, const float* o, const float* d, const 
  * later renders count node / primitive fetches and tests into rt_stats; off by default.
  * The image does not depend on it. */
 int rt_set_work_counters(rt_ctx* ctx, int on);
+/* Measurement hook (no counterpart in the reference; its role is the reference's BVH::make, src/raytrace.cpp:652-788):
+ * the hierarchies rt_load_scene built over the scene and which one renders.  For each -- [0] Karras (Morton order),
+ * [1] PLOC, [2] binned surface-area build; depth 0 = not built or freed after the first render chose another --
+ * the depth and the surface-area expectation of the work of a line through the root box: node visits (box-pair
+ * tests) and exact primitive tests.  in_use: -1 before the first render of the scene, else the index kept. */
+typedef struct rt_tree_stats {
+    int32_t primitives;
+    int32_t in_use;
+    int32_t depth[3];
+    int32_t reserved;
+    double node_visits[3];
+    double prim_tests[3];
+} rt_tree_stats;
+int rt_get_tree_stats(rt_ctx* ctx, rt_tree_stats* out);
 /* on = 0: the next rt_load_scene's first render does not time the hierarchies and walks on a sample of the
  * frame (two to three extra frame times) but takes the choice that is right for most scenes -- for a caller
  * that renders ONE frame per scene, as the reference's main does (src/main.cpp:56-58).  Default on.

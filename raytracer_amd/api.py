@@ -13,7 +13,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "libraytracer_amd.so")     # RT_LIB: another build of the same library (experiments)
 
 RT_OK = 0
 (RT_ERR_INVALID, RT_ERR_IO, RT_ERR_PARSE, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NOMEM, RT_ERR_UNSUPPORTED,
@@ -22,6 +22,8 @@ RT_LIGHT_AMBIENT, RT_LIGHT_DIRECTIONAL, RT_LIGHT_POINT, RT_LIGHT_SPOT = 0, 1, 2,
 RT_PROJ_ORTHO, RT_PROJ_PERSP = 0, 1
 RT_ACCEL_AUTO, RT_ACCEL_BRUTE, RT_ACCEL_LBVH, RT_ACCEL_LBVH_PACKET, RT_ACCEL_LBVH_WIDE, RT_ACCEL_LBVH_TEAM = 0, 1, 2, 3, 4, 5
 RT_ACCEL_ALT_TREE = 16      # query_rays only: OR-ed to an LBVH mode, walks the PLOC hierarchy held until the first render
+RT_ACCEL_SAH_TREE = 32      # the same for the binned surface-area build (where load_scene built it)
+TREE_NAMES = ("karras", "ploc", "sah")
 RT_PARSE_REF_COMPAT = 1
 RT_TILE = 32
 
@@ -77,6 +79,17 @@ class RtStats(C.Structure):
                 for n, _ in self._fields_}
 
 
+class RtTreeStats(C.Structure):
+    _fields_ = [("primitives", C.c_int32), ("in_use", C.c_int32), ("depth", C.c_int32 * 3), ("reserved", C.c_int32),
+                ("node_visits", C.c_double * 3), ("prim_tests", C.c_double * 3)]
+
+    def as_dict(self) -> dict:
+        return {"in_use": TREE_NAMES[self.in_use] if self.in_use >= 0 else None,
+                "trees": {TREE_NAMES[t]: {"depth": self.depth[t], "expected_node_visits": round(self.node_visits[t], 3),
+                                          "expected_prim_tests": round(self.prim_tests[t], 3)}
+                          for t in range(3) if self.node_visits[t] > 0}}
+
+
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
 _lib = None
@@ -120,6 +133,7 @@ def load_library():
         "rt_set_work_counters": (C.c_int, [vp, C.c_int]),
         "rt_set_calibration": (C.c_int, [vp, C.c_int]),
         "rt_set_graphs": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)]),
+        "rt_get_tree_stats": (C.c_int, [vp, C.POINTER(RtTreeStats)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared entry point
@@ -134,7 +148,7 @@ EXPORTED_SYMBOLS = [
     "rt_render_device", "rt_shard_tiles", "rt_shard_bytes", "rt_render_shard", "rt_assemble_shards",
     "rt_query_rays", "rt_primary_rays", "rt_jitter_hash", "rt_parse_scene_file", "rt_free_scene",
     "rt_output_name", "rt_write_bmp24", "rt_set_work_counters", "rt_set_calibration", "rt_validate_scene", "rt_set_progress_callback",
-    "rt_set_stage_times", "rt_render_multi", "rt_assemble_shards_noalloc", "rt_set_graphs",
+    "rt_set_stage_times", "rt_render_multi", "rt_assemble_shards_noalloc", "rt_set_graphs", "rt_get_tree_stats",
 ]
 
 
@@ -429,6 +443,14 @@ class Tracer:
         if rc != RT_OK:
             raise RtError(rc, "rt_set_graphs")
         return int(n.value)
+
+    def tree_stats(self) -> RtTreeStats:
+        """The hierarchies built over the loaded scene, their surface-area cost and which one renders."""
+        ts = RtTreeStats()
+        rc = self._lib.rt_get_tree_stats(self._ctx, C.byref(ts))
+        if rc != RT_OK:
+            raise RtError(rc, "rt_get_tree_stats")
+        return ts
 
     def set_progress_callback(self, fn):
         """fn(pixels_done, pixels_total) before the first and after every batch of a render; None removes it."""

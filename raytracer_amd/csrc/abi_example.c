@@ -38,6 +38,9 @@ static int layout(void) {
     FIELD(rt_stats, ms_other); FIELD(rt_stats, launches_extend); FIELD(rt_stats, launches_shadow);
     FIELD(rt_stats, batches); FIELD(rt_stats, retries); FIELD(rt_stats, accel_used); FIELD(rt_stats, generations);
     FIELD(rt_stats, ms_host_enqueue);
+    printf("rt_tree_stats %zu\n", sizeof(rt_tree_stats));
+    FIELD(rt_tree_stats, primitives); FIELD(rt_tree_stats, in_use); FIELD(rt_tree_stats, depth); FIELD(rt_tree_stats, reserved);
+    FIELD(rt_tree_stats, node_visits); FIELD(rt_tree_stats, prim_tests);
     return 0;
 }
 

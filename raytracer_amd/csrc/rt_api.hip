@@ -143,6 +143,9 @@ static bool runtime_keeps_queues_alive() {
 }
 
 // ---------------------------------------------------------------- context
+enum { RT_TREE_KARRAS = 0, RT_TREE_PLOC = 1, RT_TREE_SAH = 2, RT_TREES = 3 };
+static const char* const kTreeName[RT_TREES] = {"Karras", "PLOC", "SAH"};
+
 struct rt_ctx {
     int device = 0;
     int num_cu = 256;
@@ -188,12 +191,15 @@ struct rt_ctx {
     float4* d_sph = nullptr; int* d_sph_mat = nullptr;
     float4* d_tri = nullptr; float4* d_tri_n = nullptr;
     float4* d_mats = nullptr; DLight* d_lights = nullptr;
-    float4* d_nodes = nullptr; int* d_prim_idx = nullptr; float4* d_leaf = nullptr;
-    // second hierarchy over the same leaves (PLOC), until calibration has picked one of the two
-    float4* d_nodes_alt = nullptr; int depth_alt = 0;
+    int* d_prim_idx = nullptr; float4* d_leaf = nullptr;
+    // The hierarchies built over the same leaf records at load time: Karras (always), PLOC, binned surface-area build
+    // (where built).  The first render keeps one (calibrate / adopt_tree) and frees the others; tree_in_use = -1 until then.
+    float4* t_nodes[RT_TREES] = {nullptr, nullptr, nullptr};
+    float4* t_wide[RT_TREES] = {nullptr, nullptr, nullptr};      // their 4-wide collapses (per-lane walks only); nullptr where not built
+    int t_depth[RT_TREES] = {0, 0, 0};
+    double t_cost[RT_TREES][2] = {{0, 0}, {0, 0}, {0, 0}};      // surface-area expectation: node visits, primitive tests (rtl_tree_cost)
+    int tree_in_use = -1;
     float region[6] = {0, 0, 0, 0, 0, 0};  // box of every point a ray of a render can start from (camera origins + primitives): what the hierarchies are conservative for
-    // 4-wide collapses of the two hierarchies (per-lane walks only); nullptr where not built
-    float4* d_wide = nullptr; float4* d_wide_alt = nullptr;
 
     // ray pool
     DPool P{};
@@ -242,9 +248,14 @@ static void drop_graphs(rt_ctx* c) {
 static void free_scene(rt_ctx* c) {
     drop_graphs(c);
     hipFree(c->d_sph); hipFree(c->d_sph_mat); hipFree(c->d_tri); hipFree(c->d_tri_n);
-    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_nodes); hipFree(c->d_nodes_alt); hipFree(c->d_wide); hipFree(c->d_wide_alt); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
+    hipFree(c->d_mats); hipFree(c->d_lights); hipFree(c->d_prim_idx); hipFree(c->d_leaf);
+    for (int t = 0; t < RT_TREES; t++) {
+        hipFree(c->t_nodes[t]); hipFree(c->t_wide[t]);
+        c->t_nodes[t] = c->t_wide[t] = nullptr; c->t_depth[t] = 0; c->t_cost[t][0] = c->t_cost[t][1] = 0;
+    }
+    c->tree_in_use = -1;
     c->d_sph = nullptr; c->d_sph_mat = nullptr; c->d_tri = nullptr; c->d_tri_n = nullptr;
-    c->d_mats = nullptr; c->d_lights = nullptr; c->d_nodes = nullptr; c->d_nodes_alt = nullptr; c->d_wide = nullptr; c->d_wide_alt = nullptr; c->d_prim_idx = nullptr; c->d_leaf = nullptr;
+    c->d_mats = nullptr; c->d_lights = nullptr; c->d_prim_idx = nullptr; c->d_leaf = nullptr;
     c->has_scene = false;
 }
 static void free_pool(rt_ctx* c) {
@@ -497,7 +508,6 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
     if (S.n_prims >= 2) {
         int radius = 16;                                     // RT_PLOC_RADIUS=0: Karras hierarchy only
         if (const char* e = getenv("RT_PLOC_RADIUS")) radius = std::max(0, std::min(256, atoi(e)));
-        int depth_k = 0;
         // 4-wide nodes with float boxes (128 B) while the tree fits the L2 caches (32 MB of them at 2^19 primitives):
         // there a walk's step is latency-bound and decoding bytes only lengthens it (K4: 2.2 ms against 2.4); beyond,
         // with 8-bit boxes (64 B): the walks are bound by the bytes they move (K5: 68 ms against 73)
@@ -519,14 +529,28 @@ extern "C" int rt_load_scene(rt_ctx* c, const rt_scene_desc* s) {
             origin_box[0] = lo.x; origin_box[1] = lo.y; origin_box[2] = lo.z;
             origin_box[3] = hi.x; origin_box[4] = hi.y; origin_box[5] = hi.z;
         }
-        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->d_nodes, &c->d_prim_idx, &c->d_leaf,
-                                             &depth_k, radius, &c->d_nodes_alt, &c->depth_alt, &c->d_wide, &c->d_wide_alt, S.wide_quant,
-                                             origin_box, c->region);
+        // the binned surface-area build pays for scenes whose frames are bound by tests per ray, not by memory: up to 2^18
+        // primitives by default (a wave per node: the top levels of a larger scene would take longer than they save)
+        int sah_max = 1 << 18;
+        if (const char* e = getenv("RT_SAH_MAX_PRIMS")) sah_max = std::max(0, atoi(e));
+        hipError_t e = (hipError_t)rtl_build(c->stream, c->d_sph, S.ns, c->d_tri, S.nt, &c->t_nodes[RT_TREE_KARRAS], &c->d_prim_idx, &c->d_leaf,
+                                             &c->t_depth[RT_TREE_KARRAS], radius, &c->t_nodes[RT_TREE_PLOC], &c->t_depth[RT_TREE_PLOC],
+                                             &c->t_wide[RT_TREE_KARRAS], &c->t_wide[RT_TREE_PLOC], S.wide_quant, origin_box, c->region,
+                                             sah_max, &c->t_nodes[RT_TREE_SAH], &c->t_depth[RT_TREE_SAH], &c->t_wide[RT_TREE_SAH]);
         if (e != hipSuccess) { rt_set_error(std::string("LBVH build: ") + hipGetErrorString(e)); return RT_ERR_HIP; }
-        S.nodes = c->d_nodes; S.nodes4 = c->d_wide; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = 0; S.depth = depth_k;
-        if (getenv("RT_VERBOSE"))
-            fprintf(stderr, "[rt bvh] %d primitives; Karras depth %d; PLOC(radius %d) depth %d%s\n", S.n_prims, depth_k, radius,
-                    c->depth_alt, c->d_nodes_alt ? "" : " (not built)");
+        for (int t = 0; t < RT_TREES; t++)
+            if (c->t_nodes[t] && rtl_tree_cost(c->stream, c->t_nodes[t], S.n_prims - 1, c->t_cost[t]) != (int)hipSuccess) (void)hipGetLastError();
+        S.nodes = c->t_nodes[RT_TREE_KARRAS]; S.nodes4 = c->t_wide[RT_TREE_KARRAS]; S.prim_idx = c->d_prim_idx; S.leaf = c->d_leaf; S.root = 0;
+        S.depth = c->t_depth[RT_TREE_KARRAS];
+        if (getenv("RT_VERBOSE")) {
+            fprintf(stderr, "[rt bvh] %d primitives;", S.n_prims);
+            for (int t = 0; t < RT_TREES; t++) {
+                if (c->t_nodes[t]) fprintf(stderr, " %s depth %d, expected node visits %.2f + primitive tests %.2f per line through the root box;",
+                                           kTreeName[t], c->t_depth[t], c->t_cost[t][0], c->t_cost[t][1]);
+                else fprintf(stderr, " %s not built;", kTreeName[t]);
+            }
+            fprintf(stderr, " PLOC radius %d\n", radius);
+        }
     } else {
         accel = RT_ACCEL_BRUTE;
     }
@@ -940,20 +964,31 @@ static int run_batch(rt_ctx* c, uint32_t tile0, uint32_t ntiles, int shard_mode,
     return RT_OK;
 }
 
-// Keeps one of the two hierarchies built at load time and frees the other.
-static void adopt_tree(rt_ctx* c, bool use_alt) {
-    if (c->d_nodes_alt) {
-        if (use_alt) {
-            std::swap(c->d_nodes, c->d_nodes_alt);
-            std::swap(c->d_wide, c->d_wide_alt);
-            c->S.depth = c->depth_alt;
-        }
-        hipFree(c->d_nodes_alt); hipFree(c->d_wide_alt);
-        c->d_nodes_alt = nullptr; c->d_wide_alt = nullptr;
+// Keeps hierarchy `which` of those built at load time (Karras if it does not exist) and frees the others.
+static void adopt_tree(rt_ctx* c, int which) {
+    if (c->tree_in_use >= 0) return;
+    if (which < 0 || which >= RT_TREES || !c->t_nodes[which]) which = RT_TREE_KARRAS;
+    for (int t = 0; t < RT_TREES; t++) {
+        if (t == which) continue;
+        hipFree(c->t_nodes[t]); hipFree(c->t_wide[t]);
+        c->t_nodes[t] = c->t_wide[t] = nullptr;
     }
-    c->S.nodes = c->d_nodes;
-    c->S.nodes4 = c->d_wide;
+    c->tree_in_use = which;
+    c->S.nodes = c->t_nodes[which];
+    c->S.nodes4 = c->t_wide[which];
+    c->S.depth = c->t_depth[which];
     c->S.root = 0;
+}
+
+// The choice when nothing is measured: the binned surface-area build where it exists, else PLOC on meshes of up to
+// 2^20 primitives, Karras on huge uniform clouds; RT_TREE=karras|ploc|sah overrides.
+static int default_tree(const rt_ctx* c) {
+    int t = c->t_nodes[RT_TREE_SAH] ? RT_TREE_SAH : (c->S.n_prims <= (1 << 20) && c->t_nodes[RT_TREE_PLOC]) ? RT_TREE_PLOC : RT_TREE_KARRAS;
+    if (const char* e = getenv("RT_TREE")) {
+        for (int k = 0; k < RT_TREES; k++)
+            if (!strcasecmp(e, kTreeName[k]) && c->t_nodes[k]) t = k;
+    }
+    return t;
 }
 
 // Picks the hierarchy (Karras or PLOC, when both were built) and, per ray generation, the
@@ -967,8 +1002,7 @@ static void adopt_tree(rt_ctx* c, bool use_alt) {
 static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     c->tuned = true;
     if (c->accel != RT_ACCEL_LBVH || c->forced_modes || !c->calibration || c->tiles.empty()) {
-        // no measurement: PLOC pays off on meshes, Karras on huge uniform clouds
-        adopt_tree(c, c->S.n_prims <= (1 << 20));
+        adopt_tree(c, default_tree(c));
         return RT_OK;
     }
     DScene& S = c->S;
@@ -976,10 +1010,17 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     const uint64_t per_tile = (uint64_t)RT_TILE_AREA * spp;
     const uint32_t total = (uint32_t)c->tiles.size();
     const int G = S.max_depth + 1;
-    const int ntrees = c->d_nodes_alt ? 2 : 1;
-    const float4* tree_nodes[2] = {c->d_nodes, c->d_nodes_alt};
-    const float4* tree_wide[2] = {c->d_wide, c->d_wide_alt};
-    const int tree_depth[2] = {S.depth, c->depth_alt};
+    // candidates: every hierarchy that was built -- except Karras where the surface-area build exists (on scenes that
+    // small it never won a timing, and every candidate costs a trial frame)
+    // (RT_TREE=karras|ploc|sah: that hierarchy and no other; RT_CALIBRATE_ALL=1: all of them)
+    int cand[RT_TREES], ntrees = 0;
+    for (int t = 0; t < RT_TREES; t++)
+        if (c->t_nodes[t] && !(t == RT_TREE_KARRAS && c->t_nodes[RT_TREE_SAH] && !getenv("RT_CALIBRATE_ALL"))) cand[ntrees++] = t;
+    if (const char* e = getenv("RT_TREE"))
+        for (int t = 0; t < RT_TREES; t++)
+            if (c->t_nodes[t] && !strcasecmp(e, kTreeName[t])) { cand[0] = t; ntrees = 1; }
+    const float4* tree_nodes[RT_TREES]; const float4* tree_wide[RT_TREES]; int tree_depth[RT_TREES];
+    for (int k = 0; k < ntrees; k++) { tree_nodes[k] = c->t_nodes[cand[k]]; tree_wide[k] = c->t_wide[cand[k]]; tree_depth[k] = c->t_depth[cand[k]]; }
     std::vector<hipEvent_t> ev((size_t)G * 4, nullptr);
     uint32_t* d_pick = nullptr;
     auto cleanup = [&]() {
@@ -990,7 +1031,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
 #define CAL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rt_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return (e_ == hipErrorOutOfMemory) ? RT_ERR_NOMEM : RT_ERR_HIP; } } while (0)
     for (auto& e : ev) CAL_TRY(hipEventCreate(&e));
     // [tree][walk mode][generation], milliseconds
-    struct Times { float v[2][6][RT_MAX_GEN + 1]; };
+    struct Times { float v[RT_TREES][6][RT_MAX_GEN + 1]; };
     std::vector<Times> times(2);
     auto& te = times[0].v;
     auto& tsh = times[1].v;
@@ -1068,17 +1109,14 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
     cleanup();
 #undef CAL_TRY
     if (ok) {
-        float best_total[2] = {0, 0};
+        float best_total[RT_TREES] = {0, 0, 0};
         for (int t = 0; t < ntrees; t++)
             for (int g = 0; g < G; g++)
                 best_total[t] += std::min(std::min(te[t][2][g], te[t][5][g]), std::min(te[t][3][g], te[t][4][g])) +
                                  std::min(std::min(tsh[t][2][g], tsh[t][5][g]), std::min(tsh[t][3][g], tsh[t][4][g]));
-        int t = (ntrees == 2 && best_total[1] < best_total[0]) ? 1 : 0;
-        if (const char* e = getenv("RT_TREE")) {             // "karras" / "ploc": override the measurement
-            if (!strcmp(e, "karras")) t = 0;
-            else if (!strcmp(e, "ploc") && ntrees == 2) t = 1;
-        }
-        adopt_tree(c, t == 1);
+        int t = 0;
+        for (int k = 1; k < ntrees; k++) if (best_total[k] < best_total[t]) t = k;
+        adopt_tree(c, cand[t]);
         // first guess of the rays per generation of a whole batch, until a frame has been counted
         for (int g = 0; g < G; g++)
             c->gen_rays[g] = (uint64_t)((double)sample_rays[g] * ((double)tiles_per_batch * (double)per_tile) / ((double)n * (double)per_tile));
@@ -1095,10 +1133,10 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
             c->mode_shadow[g] = (int8_t)best_of(tsh[t][2][g], tsh[t][3][g], tsh[t][4][g], tsh[t][5][g]);
         }
         if (getenv("RT_VERBOSE")) {
-            fprintf(stderr, "[rt calibrate] %u tiles; traversal ms Karras %.3f", n, best_total[0]);
-            if (ntrees == 2) fprintf(stderr, ", PLOC %.3f", best_total[1]);
+            fprintf(stderr, "[rt calibrate] %u tiles; traversal ms", n);
+            for (int k = 0; k < ntrees; k++) fprintf(stderr, "%s %s %.3f", k ? "," : "", kTreeName[cand[k]], best_total[k]);
             const char* tag = "?-LPWT";
-            fprintf(stderr, " -> %s; extend (lane/packet/wide/team ms):", t ? "PLOC" : "Karras");
+            fprintf(stderr, " -> %s; extend (lane/packet/wide/team ms):", kTreeName[cand[t]]);
             for (int g = 0; g < G; g++) fprintf(stderr, " g%d %.3f/%.3f/%.3f/%.3f->%c", g, te[t][2][g] > 1e29f ? 0.0f : te[t][2][g], te[t][3][g], te[t][4][g] > 1e29f ? 0.0f : te[t][4][g], te[t][5][g] > 1e29f ? 0.0f : te[t][5][g], tag[c->mode_extend[g]]);
             fprintf(stderr, "; rays:");
             for (int g = 0; g < G; g++) fprintf(stderr, " g%d %u", g, sample_rays[g]);
@@ -1107,7 +1145,7 @@ static int calibrate(rt_ctx* c, uint32_t tiles_per_batch) {
             fprintf(stderr, "\n");
         }
     } else {
-        adopt_tree(c, c->S.n_prims <= (1 << 20));
+        adopt_tree(c, default_tree(c));
         if (getenv("RT_VERBOSE"))
             fprintf(stderr, "[rt calibrate] no sample fitted the ray pool: keeping the packet walk everywhere\n");
     }
@@ -1512,12 +1550,14 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
                              int any_hit, int accel, int32_t* prim_out, float* dist2_out) {
     if (!c || n < 0 || !o || !d || !prim_out) return RT_ERR_INVALID;
     if (!c->has_scene) return RT_ERR_NO_SCENE;
-    const bool alt = (accel & RT_ACCEL_ALT_TREE) != 0;
-    accel &= ~RT_ACCEL_ALT_TREE;
+    // a hierarchy other than the one in use (or, before the first render, than Karras): held until the first render
+    const int other = (accel & RT_ACCEL_ALT_TREE) ? RT_TREE_PLOC : (accel & RT_ACCEL_SAH_TREE) ? RT_TREE_SAH : -1;
+    const bool alt = other >= 0;
+    accel &= ~(RT_ACCEL_ALT_TREE | RT_ACCEL_SAH_TREE);
     if (accel != RT_ACCEL_BRUTE && accel != RT_ACCEL_LBVH && accel != RT_ACCEL_LBVH_PACKET && accel != RT_ACCEL_LBVH_WIDE &&
         accel != RT_ACCEL_LBVH_TEAM) return RT_ERR_INVALID;
-    if (alt && (accel == RT_ACCEL_BRUTE || !c->d_nodes_alt)) {
-        rt_set_error("no second hierarchy is held (none was built, or a render has already chosen)");
+    if (alt && (accel == RT_ACCEL_BRUTE || !c->t_nodes[other] || (c->tree_in_use >= 0 && c->tree_in_use != other))) {
+        rt_set_error("that hierarchy is not held (it was not built, or a render has already chosen another)");
         return RT_ERR_UNSUPPORTED;
     }
     if (accel != RT_ACCEL_BRUTE && !c->S.nodes) { rt_set_error("scene has fewer than 2 primitives: no LBVH"); return RT_ERR_UNSUPPORTED; }
@@ -1546,7 +1586,7 @@ extern "C" int rt_query_rays(rt_ctx* c, int64_t n, const float* o, const float* 
     Q_TRY(hipMemcpyAsync(d_d, d, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (dmax) Q_TRY(hipMemcpyAsync(d_m, dmax, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     DScene Sq = c->S;
-    if (alt) { Sq.nodes = c->d_nodes_alt; Sq.nodes4 = c->d_wide_alt; Sq.depth = c->depth_alt; Sq.root = 0; }
+    if (alt) { Sq.nodes = c->t_nodes[other]; Sq.nodes4 = c->t_wide[other]; Sq.depth = c->t_depth[other]; Sq.root = 0; }
     if ((accel == RT_ACCEL_LBVH_WIDE || accel == RT_ACCEL_LBVH_TEAM) && !Sq.nodes4) {
         cleanup();
         rt_set_error("no 4-wide collapse of this hierarchy was built (tree deeper than 64)");
@@ -1602,6 +1642,20 @@ extern "C" int rt_set_graphs(rt_ctx* c, int on, uint64_t* replays) {
         }
     }
     if (replays) *replays = c->graph_replays;
+    return RT_OK;
+}
+
+extern "C" int rt_get_tree_stats(rt_ctx* c, rt_tree_stats* out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    if (!c->has_scene) return RT_ERR_NO_SCENE;
+    *out = rt_tree_stats{};
+    out->primitives = c->S.n_prims;
+    out->in_use = c->tree_in_use;
+    for (int t = 0; t < RT_TREES; t++) {
+        out->depth[t] = c->t_nodes[t] ? c->t_depth[t] : 0;
+        out->node_visits[t] = c->t_cost[t][0];
+        out->prim_tests[t] = c->t_cost[t][1];
+    }
     return RT_OK;
 }
 

@@ -54,4 +54,7 @@ void rtk_primary_rays(hipStream_t st, const DCamera& cam, int64_t n, const int* 
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes,
               int** prim_idx, float4** leaf, int* depth, int ploc_radius, float4** ploc_nodes, int* ploc_depth,
               float4** wide_nodes, float4** ploc_wide_nodes, int wide_quantised, const float* origin_box,
-              float* region_out);
+              float* region_out, int sah_max_prims, float4** sah_nodes, int* sah_depth, float4** sah_wide_nodes);
+// Surface-area cost of a binary hierarchy of m inner nodes (root 0): out[0] = expected node visits, out[1] = expected
+// exact primitive tests of a random line through the root box.  Returns a hipError_t as int.
+int rtl_tree_cost(hipStream_t st, const float4* nodes, int m, double out[2]);

@@ -440,6 +440,210 @@ static int ploc_build(hipStream_t st, const Box* boxes, const uint32_t* sorted, 
     return (int)hipSuccess;
 }
 
+// ---------------------------------------------------------------- binned surface-area build
+// Top-down build by the surface-area heuristic with 16 bins per axis (Wald 2007), for scenes small enough that a
+// few milliseconds at load time buy the cheapest tree to walk: every frame of a scene of 10^4 .. 10^5 primitives is
+// bound by the number of node and primitive tests per ray, and a greedy top-down split chooses exactly for that.
+// One launch per level of the tree; a WAVE per node: its lanes stride over the node's primitives (Morton slots, held
+// in two index arrays that alternate by level), bin their box centres along the three axes (boxes and counts per bin
+// in LDS, atomics), 45 lanes price the 3 x 15 candidate planes, and the node's primitives are partitioned by the
+// cheapest one (ballot + prefix counts).  Leaves hold one primitive, as in the other hierarchies, and share their
+// leaf records (reference = ~Morton slot).  Node ids are pre-order positions -- a node of k primitives has k - 1
+// inner nodes below it, so left child = id + 1, right child = id + (primitives on the left) -- which is also the
+// memory order a descending walk wants.  Child boxes are unions of the padded primitive boxes: conservative like
+// every other tree here.  Centres that all fall into one bin (coincident primitives) are split by index.
+#define SAH_BINS 16
+struct SahNode { int b, e, id; };
+
+__device__ __forceinline__ float wave_min_f(float v) { for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off)); return v; }
+__device__ __forceinline__ float wave_max_f(float v) { for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off)); return v; }
+__device__ __forceinline__ int wave_max_i(int v) { for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off)); return v; }
+
+__global__ __launch_bounds__(256) void k_sah_level(const Box* __restrict__ sbox /* boxes in Morton-slot order */, const uint32_t* __restrict__ idx_in,
+                                                   uint32_t* __restrict__ idx_out, const SahNode* __restrict__ todo, int ntodo,
+                                                   SahNode* __restrict__ next, int* next_count, float4* __restrict__ nodes) {
+    __shared__ uint32_t s_box[4][3][SAH_BINS][6];
+    __shared__ uint32_t s_cnt[4][3][SAH_BINS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t (*bbox)[SAH_BINS][6] = s_box[wv];
+    uint32_t (*bcnt)[SAH_BINS] = s_cnt[wv];
+    for (int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < ntodo; t += nwaves) {
+        const SahNode nd = todo[t];
+        const int b = nd.b, e = nd.e, cnt = nd.e - nd.b;
+        // ---- bounds of the box centres
+        float cmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, cmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        for (int i = b + lane; i < e; i += 64) {
+            const Box bx = sbox[idx_in[i]];
+            for (int k = 0; k < 3; k++) {
+                const float c = 0.5f * (bx.lo[k] + bx.hi[k]);
+                if (c == c) { cmin[k] = fminf(cmin[k], c); cmax[k] = fmaxf(cmax[k], c); }
+            }
+        }
+        float scale[3];
+        for (int k = 0; k < 3; k++) {
+            cmin[k] = wave_min_f(cmin[k]); cmax[k] = wave_max_f(cmax[k]);
+            const float ext = cmax[k] - cmin[k];
+            scale[k] = (ext > 0.0f && ext < __builtin_inff()) ? (float)SAH_BINS * 0.99999f / ext : 0.0f;
+        }
+        // ---- binning
+        for (int q = lane; q < 3 * SAH_BINS; q += 64) {
+            uint32_t* bb = bbox[q / SAH_BINS][q % SAH_BINS];
+            bb[0] = bb[1] = bb[2] = 0xFFFFFFFFu; bb[3] = bb[4] = bb[5] = 0u;
+            bcnt[q / SAH_BINS][q % SAH_BINS] = 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        auto bin_of = [&](const Box& bx, int k) {
+            const float c = 0.5f * (bx.lo[k] + bx.hi[k]);
+            int q = (c == c) ? (int)((c - cmin[k]) * scale[k]) : 0;
+            return q < 0 ? 0 : (q > SAH_BINS - 1 ? SAH_BINS - 1 : q);
+        };
+        for (int i = b + lane; i < e; i += 64) {
+            const Box bx = sbox[idx_in[i]];
+            for (int k = 0; k < 3; k++) {
+                const int q = bin_of(bx, k);
+                uint32_t* bb = bbox[k][q];
+                for (int a = 0; a < 3; a++) {
+                    if (bx.lo[a] == bx.lo[a]) atomicMin(&bb[a], f2ord(bx.lo[a]));
+                    if (bx.hi[a] == bx.hi[a]) atomicMax(&bb[3 + a], f2ord(bx.hi[a]));
+                }
+                atomicAdd(&bcnt[k][q], 1u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- price the 3 x 15 planes: lane = axis * 15 + plane (left = bins 0 .. plane)
+        float cost = __builtin_inff();
+        Box L, R;
+        int nL = 0;
+        for (int a = 0; a < 3; a++) { L.lo[a] = R.lo[a] = __builtin_inff(); L.hi[a] = R.hi[a] = -__builtin_inff(); }
+        if (lane < 3 * (SAH_BINS - 1)) {
+            const int k = lane / (SAH_BINS - 1), pl = lane % (SAH_BINS - 1);
+            int nR = 0;
+            for (int q = 0; q < SAH_BINS; q++) {
+                const uint32_t c = bcnt[k][q];
+                if (!c) continue;
+                Box& T = q <= pl ? L : R;
+                (q <= pl ? nL : nR) += (int)c;
+                for (int a = 0; a < 3; a++) {
+                    if (bbox[k][q][a] != 0xFFFFFFFFu) T.lo[a] = fminf(T.lo[a], ord2f(bbox[k][q][a]));
+                    if (bbox[k][q][3 + a] != 0u) T.hi[a] = fmaxf(T.hi[a], ord2f(bbox[k][q][3 + a]));
+                }
+            }
+            auto area = [](const Box& T) {
+                const float dx = T.hi[0] - T.lo[0], dy = T.hi[1] - T.lo[1], dz = T.hi[2] - T.lo[2];
+                return (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? dx * dy + dy * dz + dz * dx : 0.0f;
+            };
+            if (nL > 0 && nR > 0) {
+                cost = area(L) * (float)nL + area(R) * (float)nR;
+                if (!(cost == cost)) cost = 3.0e38f;               // boxes with infinite faces: any plane that separates does
+            }
+        }
+        // cheapest plane, ties to the lowest lane
+        unsigned long long key = ((unsigned long long)__float_as_uint(cost) << 32) | (unsigned)lane;    // cost >= 0: bit order = value order
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(key, off); key = o < key ? o : key; }
+        const int win = (int)(unsigned)key;
+        const bool by_index = !(__uint_as_float((uint32_t)(key >> 32)) < __builtin_inff());    // no plane separates the centres
+        const int axis = by_index ? 0 : win / (SAH_BINS - 1), plane = by_index ? 0 : win % (SAH_BINS - 1);
+        int nl = by_index ? cnt / 2 : __shfl(nL, win);
+        // ---- partition; the winner's child boxes travel from its lane, or are gathered again for a split by index
+        int offL = 0, offR = 0, firstL = -1, firstR = -1;
+        Box UL, UR;
+        for (int a = 0; a < 3; a++) { UL.lo[a] = UR.lo[a] = __builtin_inff(); UL.hi[a] = UR.hi[a] = -__builtin_inff(); }
+        for (int base = b; base < e; base += 64) {
+            const int i = base + lane;
+            const bool in = i < e;
+            uint32_t slot = 0; bool left = false;
+            Box bx;
+            if (in) {
+                slot = idx_in[i];
+                bx = sbox[slot];
+                left = by_index ? (i - b) < nl : bin_of(bx, axis) <= plane;
+            }
+            const unsigned long long ml = __builtin_amdgcn_ballot_w64(in && left), mr = __builtin_amdgcn_ballot_w64(in && !left);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (in) {
+                const int dst = left ? b + offL + __popcll(ml & below) : b + nl + offR + __popcll(mr & below);
+                idx_out[dst] = slot;
+                if (dst == b) firstL = (int)slot;
+                if (dst == b + nl) firstR = (int)slot;
+                if (by_index) {
+                    Box& T = left ? UL : UR;
+                    for (int a = 0; a < 3; a++) { T.lo[a] = fminf(T.lo[a], bx.lo[a]); T.hi[a] = fmaxf(T.hi[a], bx.hi[a]); }
+                }
+            }
+            offL += __popcll(ml); offR += __popcll(mr);
+        }
+        firstL = wave_max_i(firstL); firstR = wave_max_i(firstR);
+        float f[12];
+        for (int a = 0; a < 3; a++) {
+            if (by_index) {
+                f[2 * a] = wave_min_f(UL.lo[a]); f[2 * a + 1] = wave_max_f(UL.hi[a]);
+                f[6 + 2 * a] = wave_min_f(UR.lo[a]); f[6 + 2 * a + 1] = wave_max_f(UR.hi[a]);
+            } else {
+                f[2 * a] = __shfl(L.lo[a], win); f[2 * a + 1] = __shfl(L.hi[a], win);
+                f[6 + 2 * a] = __shfl(R.lo[a], win); f[6 + 2 * a + 1] = __shfl(R.hi[a], win);
+            }
+        }
+        if (lane == 0) {
+            const int nr = cnt - nl;
+            const int refL = nl == 1 ? ~firstL : nd.id + 1, refR = nr == 1 ? ~firstR : nd.id + nl;
+            float4* dst = nodes + 4 * (size_t)nd.id;
+            dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+            dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+            dst[2] = make_float4(f[8], f[9], f[10], f[11]);
+            dst[3] = make_float4(__int_as_float(refL), __int_as_float(refR), 0.0f, 0.0f);
+            const int kids = (nl > 1 ? 1 : 0) + (nr > 1 ? 1 : 0);
+            if (kids) {
+                int at = atomicAdd(next_count, kids);
+                if (nl > 1) next[at++] = SahNode{b, b + nl, nd.id + 1};
+                if (nr > 1) next[at] = SahNode{b + nl, e, nd.id + nl};
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the bins are rewritten for the wave's next node
+    }
+}
+
+__global__ void k_sah_gather(const Box* boxes, const uint32_t* sorted, int n, Box* sbox, uint32_t* idx) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    sbox[j] = boxes[sorted[j]];
+    idx[j] = (uint32_t)j;
+}
+
+// boxes / sorted: padded primitive boxes and the Morton order.  Fills nodes_out[n-1] (root = node 0), *depth = levels.
+// Returns a hipError_t as int; hipErrorUnknown for a tree deeper than max_depth (the caller then does without it).
+static int sah_build(hipStream_t st, const Box* boxes, const uint32_t* sorted, int n, int max_depth, float4* nodes_out, int* depth) {
+    Box* sbox = nullptr; uint32_t* idx[2] = {nullptr, nullptr}; SahNode* list[2] = {nullptr, nullptr}; int* counter = nullptr;
+    auto cleanup = [&]() { void* ptrs[] = {sbox, idx[0], idx[1], list[0], list[1], counter}; for (void* p : ptrs) (void)hipFree(p); };
+#define S_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return (int)e_; } } while (0)
+    S_TRY(hipMalloc(&sbox, (size_t)n * sizeof(Box)));
+    for (int k = 0; k < 2; k++) { S_TRY(hipMalloc(&idx[k], (size_t)n * 4)); S_TRY(hipMalloc(&list[k], (size_t)n * sizeof(SahNode))); }
+    S_TRY(hipMalloc(&counter, 4));
+    hipLaunchKernelGGL(k_sah_gather, dim3((n + 255) / 256), dim3(256), 0, st, boxes, sorted, n, sbox, idx[0]);
+    const SahNode root{0, n, 0};
+    S_TRY(hipMemcpyAsync(list[0], &root, sizeof(root), hipMemcpyHostToDevice, st));
+    S_TRY(hipStreamSynchronize(st));                         // root is a local
+    int todo = 1, level = 0;
+    while (todo > 0) {
+        if (level >= max_depth) { cleanup(); return (int)hipErrorUnknown; }
+        S_TRY(hipMemsetAsync(counter, 0, 4, st));
+        const int blocks = std::min(1024, (todo + 3) / 4);
+        hipLaunchKernelGGL(k_sah_level, dim3(blocks), dim3(256), 0, st, (const Box*)sbox, (const uint32_t*)idx[level & 1], idx[(level + 1) & 1],
+                           (const SahNode*)list[level & 1], todo, list[(level + 1) & 1], counter, nodes_out);
+        S_TRY(hipGetLastError());
+        int got = 0;
+        S_TRY(hipMemcpyAsync(&got, counter, 4, hipMemcpyDeviceToHost, st));
+        S_TRY(hipStreamSynchronize(st));
+        if (got < 0 || got > n) { cleanup(); return (int)hipErrorUnknown; }
+        todo = got;
+        level++;
+    }
+    *depth = level;
+    cleanup();
+#undef S_TRY
+    return (int)hipSuccess;
+}
+
 // ---------------------------------------------------------------- 4-wide collapse
 // A per-lane walk is a chain of dependent fetches; folding every second level of the binary
 // tree into its parent halves the chain.  Inner nodes at even depth survive; each takes the
@@ -587,20 +791,80 @@ static void collapse4(hipStream_t st, const float4* nodes, int m, bool quantised
     *out = wide;
 }
 
+// ---------------------------------------------------------------- tree quality
+// Surface-area cost of a binary hierarchy: a ray that crosses the root box crosses a convex box inside it with
+// probability area(box) / area(root) (for uniformly distributed lines), so
+//   out[0] = sum over inner nodes of area / area(root)   = expected node visits (box-pair tests) of such a ray,
+//   out[1] = sum over leaves of area / area(root)        = expected exact primitive tests,
+//   out[2] = area(root).
+// The two sums are what a better tree lowers; walks that stop early (any-hit, a shrinking distance bound) see less.
+__device__ inline double box_area6(const float* b) {      // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
+    const double dx = (double)b[1] - (double)b[0], dy = (double)b[3] - (double)b[2], dz = (double)b[5] - (double)b[4];
+    if (!(dx >= 0.0) || !(dy >= 0.0) || !(dz >= 0.0)) return 0.0;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+}
+__global__ void k_tree_cost(const float4* nodes, int m, double* acc /*[3]: inner, leaf, root (root written by node 0)*/) {
+    __shared__ double red[2][256];
+    double inner = 0.0, leaf = 0.0;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < m; v += gridDim.x * blockDim.x) {
+        const float* f = (const float*)(nodes + 4 * (size_t)v);
+        for (int s = 0; s < 2; s++) {
+            const double a = box_area6(f + 6 * s);
+            if (__float_as_int(f[12 + s]) >= 0) inner += a; else leaf += a;
+        }
+        if (v == 0) {
+            float u[6];
+            for (int k = 0; k < 3; k++) { u[2 * k] = fminf(f[2 * k], f[6 + 2 * k]); u[2 * k + 1] = fmaxf(f[2 * k + 1], f[6 + 2 * k + 1]); }
+            const double a = box_area6(u);
+            acc[2] = a;
+            inner += a;
+        }
+    }
+    red[0][threadIdx.x] = inner; red[1][threadIdx.x] = leaf;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(&acc[0], red[0][0]); atomicAdd(&acc[1], red[1][0]); }
+}
+
+// nodes: binary tree of m inner nodes, root 0.  out[0] expected node visits, out[1] expected primitive tests (see above).
+int rtl_tree_cost(hipStream_t st, const float4* nodes, int m, double out[2]) {
+    out[0] = out[1] = 0.0;
+    if (!nodes || m < 1) return (int)hipSuccess;
+    double* acc = nullptr;
+    hipError_t e = hipMalloc(&acc, 3 * sizeof(double));
+    if (e != hipSuccess) return (int)e;
+    double h[3] = {0, 0, 0};
+    if ((e = hipMemsetAsync(acc, 0, 3 * sizeof(double), st)) == hipSuccess) {
+        const int blocks = (m + 255) / 256;
+        hipLaunchKernelGGL(k_tree_cost, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, nodes, m, acc);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, acc, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(acc);
+    if (e == hipSuccess && h[2] > 0.0) { out[0] = h[0] / h[2]; out[1] = h[1] / h[2]; }
+    return (int)e;
+}
+
 #define L_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); (void)hipFree(nodes); (void)hipFree(vals2); (void)hipFree(leaf); return (int)e_; } } while (0)
 
-// Builds the Karras hierarchy (nodes_out, at most 95 deep; wide_out = its 4-wide collapse or nullptr)
-// and, when ploc_radius > 0, a PLOC hierarchy over the same Morton order (ploc_out; nullptr if it failed or came out deeper
-// than the 64-entry stacks of the fast walks allow).  Both share the leaf records and have
+// Builds the Karras hierarchy (nodes_out, at most 95 deep; wide_out = its 4-wide collapse or nullptr),
+// when ploc_radius > 0 a PLOC hierarchy over the same Morton order (ploc_out; nullptr if it failed or came out deeper
+// than the 64-entry stacks of the fast walks allow) and, for scenes of at most sah_max_prims primitives, a binned
+// surface-area build (sah_out, same conditions).  All share the leaf records and have
 // their root at node 0; which one traverses faster depends on the scene and is measured
 // by the caller.
 int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int nt, float4** nodes_out,
               int** prim_idx_out, float4** leaf_out, int* depth, int ploc_radius, float4** ploc_out,
               int* ploc_depth, float4** wide_out, float4** ploc_wide_out, int wide_quantised, const float* origin_box,
-              float* region_out) {
+              float* region_out, int sah_max_prims, float4** sah_out, int* sah_depth, float4** sah_wide_out) {
     int n = ns + nt;
     *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *ploc_out = nullptr; *ploc_depth = 0;
     *wide_out = nullptr; *ploc_wide_out = nullptr;
+    *sah_out = nullptr; *sah_depth = 0; *sah_wide_out = nullptr;
     if (n < 2) return (int)hipErrorInvalidValue;
     Box* boxes = nullptr; uint32_t* scene = nullptr;   // scene[0..5] centre bounds, [6] tree depth, [8..13] region of ray origins
     unsigned long long *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;
@@ -664,6 +928,18 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
             collapse4(st, pn, n - 1, wide_quantised != 0, ploc_wide_out);
         } else {
             (void)hipFree(pn);
+            (void)hipGetLastError();
+        }
+    }
+    if (n <= sah_max_prims) {
+        float4* sn = nullptr;
+        int d = 0;
+        if (hipMalloc(&sn, (size_t)(n - 1) * 4 * sizeof(float4)) == hipSuccess &&
+            sah_build(st, boxes, vals2, n, 64, sn, &d) == (int)hipSuccess) {
+            *sah_out = sn; *sah_depth = d;
+            collapse4(st, sn, n - 1, wide_quantised != 0, sah_wide_out);
+        } else {
+            (void)hipFree(sn);
             (void)hipGetLastError();
         }
     }

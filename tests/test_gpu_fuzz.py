@@ -43,7 +43,7 @@ def test_random_scene_every_walk_against_the_oracle(oracle, monkeypatch, seed):
     orgb, orgbf, cnt, _ = oracle.render(scene, threads=16)
     variants = [("brute", ra.RT_ACCEL_BRUTE, {}), ("calibrated", ra.RT_ACCEL_LBVH, {})]
     for walk, env in WALKS.items():
-        for tree in ("karras", "ploc"):
+        for tree in ("karras", "ploc", "sah"):
             variants.append((f"{walk}/{tree}", ra.RT_ACCEL_LBVH, dict(env, RT_TREE=tree)))
     for label, accel, env in variants:
         if accel == ra.RT_ACCEL_LBVH and len(scene.spheres) + len(scene.tri_verts) < 2:
@@ -94,7 +94,8 @@ def test_rays_grazing_triangle_edges_from_far_origins(trial):
         pb, db = t.query_rays(o, d, accel=ra.RT_ACCEL_BRUTE)
         assert 0.2 < (pb >= 0).mean() < 0.8, "the rays are meant to sit on the edge between hit and miss"
         for walk in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_TEAM,
-                     ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE):
+                     ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE,
+                     ra.RT_ACCEL_LBVH_PACKET | ra.RT_ACCEL_SAH_TREE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_SAH_TREE):
             pl, dl = t.query_rays(o, d, accel=walk)
             assert np.array_equal(pb, pl), f"walk {walk}: {(pb != pl).sum()} of {len(pb)} closest hits differ"
             assert np.array_equal(bits(db[pb >= 0]), bits(dl[pb >= 0]))

@@ -155,10 +155,17 @@ def test_primary_rays_and_closest_hits_known_answers(oracle, tracer, kat, key, s
         assert np.array_equal(d2[hit].astype(np.float64), ref_hit[hit, 4])   # reference dist (squared)
 
 
-# every walk of every hierarchy: per-lane / packet / per-lane 4-wide / team of lanes per ray, on the Karras and on the PLOC tree
-TREE_WALKS = (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_TEAM,
-              ra.RT_ACCEL_LBVH | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_PACKET | ra.RT_ACCEL_ALT_TREE,
-              ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_TEAM | ra.RT_ACCEL_ALT_TREE)
+# every walk of every hierarchy: per-lane / packet / per-lane 4-wide / team of lanes per ray, on the Karras, the PLOC and
+# the binned surface-area tree
+TREE_WALKS = tuple(w | t for t in (0, ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_SAH_TREE)
+                   for w in (ra.RT_ACCEL_LBVH, ra.RT_ACCEL_LBVH_PACKET, ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_TEAM))
+
+
+def walks_held(t):
+    """TREE_WALKS without the walks of a hierarchy that was not built for the scene loaded in tracer t (the binned
+    surface-area build is left out for scenes beyond 2^18 primitives)"""
+    depth = t.tree_stats().depth
+    return tuple(w for w in TREE_WALKS if depth[2 if w & ra.RT_ACCEL_SAH_TREE else 1 if w & ra.RT_ACCEL_ALT_TREE else 0] > 0)
 
 
 def _random_rays(scene, n, rng):
@@ -222,8 +229,8 @@ def test_quantised_wide_nodes_equal_brute_force(monkeypatch, name):
         dmax = np.where(rng.random(len(o)) < 0.5, db * rng.uniform(0.5, 1.5, len(o)).astype(np.float32), np.float32(np.inf)).astype(np.float32)
         dmax[~np.isfinite(dmax)] = np.inf
         ab, _ = t.query_rays(o, d, dmax=dmax, any_hit=True, accel=ra.RT_ACCEL_BRUTE)
-        for accel in (ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE,
-                      ra.RT_ACCEL_LBVH_TEAM, ra.RT_ACCEL_LBVH_TEAM | ra.RT_ACCEL_ALT_TREE):
+        for accel in (ra.RT_ACCEL_LBVH_WIDE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_WIDE | ra.RT_ACCEL_SAH_TREE,
+                      ra.RT_ACCEL_LBVH_TEAM, ra.RT_ACCEL_LBVH_TEAM | ra.RT_ACCEL_ALT_TREE, ra.RT_ACCEL_LBVH_TEAM | ra.RT_ACCEL_SAH_TREE):
             pl, dl = t.query_rays(o, d, accel=accel)
             assert np.array_equal(pb, pl), f"accel {accel}: {(pb != pl).sum()} closest hits differ"
             assert np.array_equal(bits(db), bits(dl))
@@ -319,17 +326,24 @@ def test_synthetic_scene_lbvh_equals_brute_force(tracer):
         assert np.array_equal(bits(db), bits(dl))
 
 
-def test_both_hierarchies_render_the_same_image(tracer, monkeypatch):
-    """The first render picks Karras or PLOC by timing; force each in turn and compare."""
+def test_every_hierarchy_renders_the_same_image(tracer, monkeypatch):
+    """The first render picks a hierarchy by timing; force each of the three in turn and compare.  Their surface-area
+    costs are reported, and the one that rendered is the one that was asked for."""
     scene = load_scene("dragon").copy(width=192, height=128, spp=2)
-    monkeypatch.setenv("RT_TREE", "karras")
-    tracer.load_scene(scene)
-    rgb_k, f_k, st_k = tracer.render(want_float=True)
-    monkeypatch.setenv("RT_TREE", "ploc")
-    tracer.load_scene(scene)
-    rgb_p, f_p, st_p = tracer.render(want_float=True)
-    assert np.array_equal(rgb_k, rgb_p) and np.array_equal(bits(f_k), bits(f_p))
-    assert st_k.rays == st_p.rays
+    frames = {}
+    for k, tree in enumerate(("karras", "ploc", "sah")):
+        monkeypatch.setenv("RT_TREE", tree)
+        tracer.load_scene(scene)
+        ts = tracer.tree_stats()
+        assert ts.in_use == -1 and ts.primitives == len(scene.tri_verts) + len(scene.spheres)
+        assert all(ts.depth[t] > 0 and ts.node_visits[t] > 1.0 and ts.prim_tests[t] > 0.5 for t in range(3)), ts.as_dict()
+        frames[tree] = tracer.render(want_float=True)
+        assert tracer.tree_stats().in_use == k, tracer.tree_stats().as_dict()
+    rgb_k, f_k, st_k = frames["karras"]
+    for tree in ("ploc", "sah"):
+        rgb_p, f_p, st_p = frames[tree]
+        assert np.array_equal(rgb_k, rgb_p) and np.array_equal(bits(f_k), bits(f_p)), tree
+        assert st_k.rays == st_p.rays
 
 
 @pytest.mark.parametrize("name,kw", [("dragon", dict(width=256, height=160, spp=4)),
@@ -586,7 +600,7 @@ def test_k5_full_scale_camera_and_surface_rays_every_walk_equals_brute_force():
         tgt = scene.spheres[rng.integers(0, len(scene.spheres), len(o2)), :3]
         d2 = (tgt - o2 + rng.normal(0, 0.3, o2.shape)).astype(np.float32)
         pb2, db2 = t.query_rays(o2, d2, accel=ra.RT_ACCEL_BRUTE)
-        for accel in TREE_WALKS:
+        for accel in walks_held(t):
             pl, dl = t.query_rays(o, d, accel=accel)
             assert np.array_equal(pb, pl), f"walk {accel}, camera rays: {(pb != pl).sum()} of {n} closest hits differ"
             assert np.array_equal(bits(db[hit]), bits(dl[hit]))

@@ -285,7 +285,8 @@ def test_header_layout_seen_by_a_c_compiler_matches_the_ctypes_binding():
     exe = os.path.join(ROOT, "raytracer_amd", "abi_example")
     assert os.path.exists(exe), "raytracer_amd/abi_example not built (make -C raytracer_amd/csrc)"
     out = subprocess.run([exe, "--layout"], check=True, capture_output=True, text=True).stdout.split("\n")
-    structs = {"rt_light": api.RtLight, "rt_scene_desc": api.RtSceneDesc, "rt_options": api.RtOptions, "rt_stats": api.RtStats}
+    structs = {"rt_light": api.RtLight, "rt_scene_desc": api.RtSceneDesc, "rt_options": api.RtOptions, "rt_stats": api.RtStats,
+               "rt_tree_stats": api.RtTreeStats}
     seen = {k: set() for k in structs}
     for line in filter(None, out):
         name, *nums = line.split()

@@ -74,7 +74,7 @@ def render(scene, accel, env, frames=1, shards=0, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs=2, default=[0, 40])
-    ap.add_argument("--trees", action="store_true", help="force each hierarchy (Karras, PLOC) in turn as well")
+    ap.add_argument("--trees", action="store_true", help="force each hierarchy (Karras, PLOC, binned surface-area build) in turn as well")
     ap.add_argument("--big", action="store_true", help="thousands of primitives, larger films (seconds of oracle time per seed)")
     ap.add_argument("--save", action="store_true", help="write the frames of a mismatch to gpurun_out/fuzz_<seed>_<variant>.npz")
     args = ap.parse_args()
@@ -86,7 +86,7 @@ def main():
         orgb, orgbf, cnt, _ = orc.render(scene, threads=int(os.environ.get("FUZZ_THREADS", "16")))
         variants = [("brute", ra.RT_ACCEL_BRUTE, {})]
         for walk, env in WALKS.items():
-            for tree in (("karras", "ploc") if args.trees else (None,)):
+            for tree in (("karras", "ploc", "sah") if args.trees else (None,)):
                 e = dict(env)
                 if tree:
                     e["RT_TREE"] = tree
