@@ -1,5 +1,6 @@
 #include "raytrace_host.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -142,6 +143,9 @@ Image* RayTrace::rayTrace(Scene& scn) {
     if (!scn.d) return nullptr;
     const rt_scene_desc& s = scn.edited;
     if (debug) std::printf("Beginning Trace\n");
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    auto t0 = clk::now();
     while ((int)ctx.size() < ngpus) {
         rt_options opt{};
         opt.accel = accel;
@@ -151,6 +155,8 @@ Image* RayTrace::rayTrace(Scene& scn) {
         if (rc != RT_OK) { std::printf("%s: %s\n", rt_strerror(rc), rt_last_error()); return nullptr; }
         ctx.push_back(c);
     }
+    wall.create = ms_since(t0);
+    t0 = clk::now();
     for (rt_ctx* c : ctx) {
         int rc = rt_load_scene(c, &s);
         if (rc != RT_OK) { std::printf("%s: %s\n", rt_strerror(rc), rt_last_error()); return nullptr; }
@@ -158,6 +164,7 @@ Image* RayTrace::rayTrace(Scene& scn) {
         rt_set_work_counters(c, detailed ? 1 : 0);
         rt_set_calibration(c, calibrate ? 1 : 0);      // one frame per process: timing the walks first costs more than it saves
     }
+    wall.load = ms_since(t0);
     if (debug) {
         // P1 / P2 / Plane Dist of the DEBUG build (src/raytrace.cpp:78-82): Scene::getPlaneDist and
         // getExtremePoints restated on the host (src/parse.cpp:275-277, src/raytrace.cpp:635-647)
@@ -181,15 +188,19 @@ Image* RayTrace::rayTrace(Scene& scn) {
     prog.lines = prog.tenper > 0 ? (prog.total + prog.tenper - 1) / prog.tenper : 1;
     rt_set_progress_callback(ctx[0], &Progress::on_batch, &prog);
     std::vector<uint8_t> rgb((size_t)s.width * s.height * 3);
+    t0 = clk::now();
     int rc = ngpus == 1 ? rt_render(ctx[0], rgb.data(), nullptr, &last)
                         : rt_render_multi(ctx.data(), ngpus, rgb.data(), &last);
     rt_set_progress_callback(ctx[0], nullptr, nullptr);
     if (rc != RT_OK) { std::printf("%s: %s\n", rt_strerror(rc), rt_last_error()); return nullptr; }
+    wall.render = ms_since(t0);
     std::printf("100%%\n");
+    t0 = clk::now();
     Image* dest = new Image(s.width, s.height);
     for (size_t i = 0; i < dest->pixels.size(); i++) {
         dest->pixels[i].r = rgb[3 * i]; dest->pixels[i].g = rgb[3 * i + 1]; dest->pixels[i].b = rgb[3 * i + 2];
     }
+    wall.convert = ms_since(t0);
     return dest;
 }
 

@@ -77,6 +77,10 @@ class RayTrace {
     RayTrace& operator=(const RayTrace&) = delete;
     Image* rayTrace(Scene& scn);
     const rt_stats& stats() const { return last; }
+    // wall-clock milliseconds of the last rayTrace(): contexts created, scene uploaded + hierarchies built, frame
+    // rendered and copied out (includes the first allocation of the ray pool), pixels converted into the Image
+    struct WallTimes { double create = 0, load = 0, render = 0, convert = 0; };
+    const WallTimes& wallTimes() const { return wall; }
     void setDebug(bool on) { debug = on; }           // the DEBUG build's lines of rayTrace (src/raytrace.cpp:45-47, :78-82)
     void setCalibration(bool on) { calibrate = on; }   // time hierarchies and walks before the (one) frame; off by default here
     void setDetailedStats(bool on) { detailed = on; } // per-stage times and traversal work counts in stats()
@@ -87,6 +91,7 @@ class RayTrace {
     int ngpus = 1;
     bool debug = false, detailed = false, calibrate = false;
     rt_stats last{};
+    WallTimes wall{};
 };
 
 }  // namespace rtamd

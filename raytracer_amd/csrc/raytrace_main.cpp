@@ -10,7 +10,9 @@
 //   --seed N            seed of the jitter sequence (sample_rate > 1)
 //   --film W H          override the film size      --spp N   override sample_rate
 //   --stats             after the trace, one JSON line: rays by class, per-stage device ms,
-//                       Mrays/s, node / primitive fetches and tests per ray
+//                       Mrays/s, node / primitive fetches and tests per ray; and after the image is written a
+//                       second one with the wall-clock split of the run (parse, contexts, scene upload + hierarchies,
+//                       frame, pixel conversion, BMP file)
 //   --stats-file PATH   the same JSON into a file instead of stdout
 //   --calibrate         time both hierarchies and every walk on a sample of the frame first and keep the
 //                       fastest per ray generation (what a library user gets by default; here one frame is
@@ -99,6 +101,7 @@ int main(int argc, char* argv[]) {
         std::exit(-1);
     }
     std::chrono::duration<double> elapsed = std::chrono::system_clock::now() - start;
+    const double parse_ms = elapsed.count() * 1e3;
     std::printf("Scene parsed in ");
     displayElapsed(elapsed.count());
     if (have_seed) data->setSeed(seed);
@@ -131,8 +134,18 @@ int main(int argc, char* argv[]) {
     char out[4096];
     rt_output_name(data->getImage().getFileName().c_str(), out, sizeof(out));
     delete data;
+    start = std::chrono::system_clock::now();
     img->Write(out);
+    elapsed = std::chrono::system_clock::now() - start;
     delete img;
+    if (stats) {
+        const RayTrace::WallTimes& w = t.wallTimes();
+        char b[512];
+        std::snprintf(b, sizeof(b), "{\"wall_ms\": {\"parse\": %.3f, \"create\": %.3f, \"load\": %.3f, \"render\": %.3f, "
+                      "\"convert\": %.3f, \"write_bmp\": %.3f}}", parse_ms, w.create, w.load, w.render, w.convert, elapsed.count() * 1e3);
+        if (stats_file.empty()) std::printf("%s\n", b);
+        else if (FILE* f = std::fopen(stats_file.c_str(), "a")) { std::fprintf(f, "%s\n", b); std::fclose(f); }
+    }
     if (debug) std::printf("Outputed image to file: %s\n", out);
     return 0;
 }

@@ -612,6 +612,7 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_pool(c);
     if (capacity > 0x7FFFFFF0ull) { rt_set_error("ray pool beyond 2^31 records"); return RT_ERR_INVALID; }
+    const auto pool_t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMalloc(&c->P.o, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.d, capacity * sizeof(float4)));
     HIP_TRY(hipMalloc(&c->P.hp, capacity * sizeof(float4)));
@@ -642,6 +643,10 @@ static int ensure_pool(rt_ctx* c, uint64_t capacity, uint64_t samples) {
     HIP_TRY(hipMalloc(&c->P.wstats, (size_t)2 * RT_MAX_WAVES * 8 * sizeof(unsigned long long)));
     c->P.capacity = (uint32_t)capacity;
     c->pool_capacity = capacity; c->scol_capacity = samples; c->occl_capacity = occl;
+    if (getenv("RT_VERBOSE"))
+        fprintf(stderr, "[rt pool] %llu rays, %llu samples: %.2f GB allocated in %.2f ms\n", (unsigned long long)capacity,
+                (unsigned long long)samples, ((double)capacity * (132.0 + 8.0 / 64 * 3 + 1 + std::max(1, c->S.nl)) + (double)samples * 16.0) / 1e9,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pool_t0).count());
     return RT_OK;
 }
 

@@ -15,6 +15,9 @@
 #include "rt_device.h"
 #include "rt_kernels.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -862,6 +865,10 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
               int* ploc_depth, float4** wide_out, float4** ploc_wide_out, int wide_quantised, const float* origin_box,
               float* region_out, int sah_max_prims, float4** sah_out, int* sah_depth, float4** sah_wide_out) {
     int n = ns + nt;
+    const bool verbose = getenv("RT_VERBOSE") != nullptr;
+    auto now_ms = [t_start = std::chrono::steady_clock::now()]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_mark = now_ms();
+    auto lap = [&](const char* what) { if (verbose) { const double t = now_ms(); fprintf(stderr, "[rt bvh build] %s %.2f ms\n", what, t - t_mark); t_mark = t; } };
     *nodes_out = nullptr; *prim_idx_out = nullptr; *leaf_out = nullptr; *ploc_out = nullptr; *ploc_depth = 0;
     *wide_out = nullptr; *ploc_wide_out = nullptr;
     *sah_out = nullptr; *sah_depth = 0; *sah_wide_out = nullptr;
@@ -919,6 +926,7 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
     L_TRY(hipStreamSynchronize(st));
     *depth = (int)dpt;
     for (int k = 0; k < 6 && region_out; k++) region_out[k] = ord2f(reg[k]);
+    lap("boxes + sort + Karras hierarchy");
     if (ploc_radius > 0) {
         float4* pn = nullptr;
         int r = 0, d = 0;
@@ -930,6 +938,7 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
             (void)hipFree(pn);
             (void)hipGetLastError();
         }
+        lap("PLOC + its 4-wide collapse");
     }
     if (n <= sah_max_prims) {
         float4* sn = nullptr;
@@ -942,11 +951,13 @@ int rtl_build(hipStream_t st, const float4* sph, int ns, const float4* tri, int 
             (void)hipFree(sn);
             (void)hipGetLastError();
         }
+        lap("binned surface-area build + its 4-wide collapse");
     }
     // 4-wide versions for the per-lane walks (their stacks hold up to 3 entries per wide level: depth <= 64)
     if (*depth <= 64) collapse4(st, nodes, n - 1, wide_quantised != 0, wide_out);
     L_TRY(hipGetLastError());
     L_TRY(hipStreamSynchronize(st));
+    lap("4-wide collapse of the Karras hierarchy");
     cleanup();
     *nodes_out = nodes;
     *prim_idx_out = (int*)vals2;   // sorted primitive ids, kept by the caller

@@ -113,11 +113,15 @@ def test_cli_flags_film_as_written_stats_and_extra_arguments(oracle, tmp_path):
     assert st["accel"] == "brute" and st["gpus"] == 1                       # 5 primitives <= bvh_threshold 500
     assert st["ms"]["extend"] > 0 and st["ms"]["shadow"] > 0 and st["ms"]["render"] >= st["ms"]["extend"]
     assert st["tests_per_ray"]["closest_hit"]["primitives"] == 5.0
+    wall = json.loads(rest[1])["wall_ms"]                                   # second line: where the run's wall clock went
+    assert set(wall) == {"parse", "create", "load", "render", "convert", "write_bmp"} and all(v >= 0 for v in wall.values())
+    assert wall["render"] >= st["ms"]["render"]
     # LBVH on the same file: same bytes, and the work counters then count node fetches
     rc, out, err = run_cli(["scene.scn", "--film-as-written", "--seed", "7", "--accel", "lbvh", "--stats-file", "st.json"], tmp_path)
     assert rc == 0, (out, err)
     assert (tmp_path / "cli_out.bmp").read_bytes() == want
-    st = json.loads((tmp_path / "st.json").read_text())
+    st, wall = [json.loads(l) for l in (tmp_path / "st.json").read_text().splitlines()]
+    assert "wall_ms" in wall
     assert st["accel"] == "lbvh" and st["fetches_per_ray"]["closest_hit"]["nodes"] > 0
 
 
