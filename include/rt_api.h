@@ -196,7 +196,11 @@ int rt_shard_tiles(int width, int height, int rank, int world);
 size_t rt_shard_bytes(int width, int height, int world);
 int rt_render_shard(rt_ctx* ctx, int rank, int world, void* d_shard, rt_stats* stats);
 /* d_all: world consecutive shard buffers of rt_shard_bytes each (device);
- * d_rgb: width*height*3 bytes (device). */
+ * d_rgb: width*height*3 bytes (device).  On a context with a stream of its own the frame is complete on return; on a
+ * context that runs on the caller's stream (rt_options.stream) the kernel is queued on that stream and returns at once
+ * -- what precedes it there (the gather) and what follows (a copy, a synchronisation) is ordered by the stream, so a
+ * frame costs one host synchronisation (the ray counters of rt_render_shard) instead of three.  The same holds for
+ * rt_assemble_shards_noalloc. */
 int rt_assemble_shards(rt_ctx* ctx, const void* d_all, int world, void* d_rgb);
 
 /* One frame on n GPUs from ONE process: ctxs[r] (any devices, the same scene loaded into each)

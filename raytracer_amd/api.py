@@ -355,6 +355,7 @@ class Tracer:
         self._lib = load_library()
         self._ctx = C.c_void_p()
         opt = RtOptions(device, accel, lbvh_threshold, batch_samples, pool_rays, stream)
+        self.stream = stream or None      # the caller's stream the context runs on (None: a stream of its own)
         rc = self._lib.rt_create(C.byref(self._ctx), C.byref(opt))
         if rc != RT_OK:
             raise RtError(rc, "rt_create")

@@ -1423,7 +1423,9 @@ extern "C" int rt_assemble_shards(rt_ctx* c, const void* d_all, int world, void*
     }
     rtk_assemble(c->stream, (const uint8_t*)d_all, rt_shard_bytes(w, h, world), world, w, h, ntx, nty, c->d_rowbase, (uint8_t*)d_rgb);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // on the context's own stream the call is complete on return; on a stream the caller gave (rt_options.stream) the
+    // kernel is queued there and ordering is the caller's, like everything else the caller puts on that stream
+    if (c->own_stream) HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -1454,7 +1456,7 @@ extern "C" int rt_assemble_shards_noalloc(rt_ctx* c, const void* d_all, int worl
     // a stream under graph capture must not be waited for; the captured work runs when the graph does
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-    if (cs == hipStreamCaptureStatusNone) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (cs == hipStreamCaptureStatusNone && c->own_stream) HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

@@ -72,7 +72,10 @@ def gather_shards(shard, rank: int, world: int, dst: int = 0):
 
 def render_frame_distributed(tracer, rank: int, world: int, device):
     """Render this rank's shard on its GPU, gather, assemble on rank 0.
-    -> (frame tensor [H,W,3] uint8 on rank 0 else None, RtStats of this rank)."""
+    -> (frame tensor [H,W,3] uint8 on rank 0 else None, RtStats of this rank).
+    When the tracer runs on torch's current stream (Tracer(stream=torch.cuda.current_stream().cuda_stream)), render,
+    gather and assemble are ordered by that stream and the frame costs ONE host synchronisation (the ray counters at
+    the end of the render); the frame tensor is then complete in stream order, not on return."""
     import torch
 
     s = tracer.scene
@@ -83,6 +86,7 @@ def render_frame_distributed(tracer, rank: int, world: int, device):
     if rank != 0:
         return None, stats
     frame = torch.empty((s.height, s.width, 3), dtype=torch.uint8, device=device)
-    torch.cuda.current_stream(device).synchronize()
+    if getattr(tracer, "stream", None) != torch.cuda.current_stream(device).cuda_stream:
+        torch.cuda.current_stream(device).synchronize()      # the gather ran on torch's stream, the tracer has its own
     tracer.assemble_shards(allsh.data_ptr(), world, frame.data_ptr())
     return frame, stats
