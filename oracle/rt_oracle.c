@@ -417,7 +417,9 @@ static double now_s(void) {
 }
 
 /* pixel loop of RayTrace::rayTrace (src/raytrace.cpp:83-122), x outer / y inner,
- * OpenMP collapse(2) schedule(static,125) as the reference's PARALLEL build. */
+ * OpenMP collapse(2) schedule(static,125) as the reference's PARALLEL build; a region too small to give every
+ * thread such a chunk (the crops the tests compare) is handed out pixel by pixel instead -- pixels do not depend on
+ * one another, so the schedule cannot change a result. */
 double orc_render(const orc_scene* s, int x0, int y0, int x1, int y1, int nthreads, uint8_t* rgb8,
                   float* rgbf, orc_counts* counts) {
     v3 p1, p2;
@@ -429,7 +431,9 @@ double orc_render(const orc_scene* s, int x0, int y0, int x1, int y1, int nthrea
     double t0 = now_s();
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
-    #pragma omp parallel for collapse(2) schedule(static, 125) reduction(+ : cp, cs, csh)
+    if ((long long)(x1 - x0) * (y1 - y0) < 125LL * omp_get_max_threads()) omp_set_schedule(omp_sched_dynamic, 1);
+    else omp_set_schedule(omp_sched_static, 125);
+    #pragma omp parallel for collapse(2) schedule(runtime) reduction(+ : cp, cs, csh)
 #endif
     for (int x = x0; x < x1; x++) {
         for (int y = y0; y < y1; y++) {

@@ -548,23 +548,34 @@ def test_k3_full_size_frame_by_brute_force_equals_the_hierarchy():
     assert (st_h.rays_primary, st_h.rays_secondary, st_h.rays_shadow) == (st_b.rays_primary, st_b.rays_secondary, st_b.rays_shadow)
 
 
-@pytest.mark.parametrize("x0,y0,shard", [(3840, 2160, True), (3012, 1796, True), (4700, 2500, False), (2200, 2900, False)])
-def test_k5_full_scene_and_film_against_oracle_crops(oracle, x0, y0, shard):
-    """The synthetic scene at full scale (10^6 spheres + 10^7 triangles) on the full 7680x4320 film, 2 spp.
-    The oracle tests every primitive for every ray (half a second per ray), so each case compares one 4x4
-    crop -- centre and off-centre, all on geometry -- in float (four cases, one crop each, so that a run
-    reports progress every minute); for two of them the crop's tile is also rendered as part of a shard of
-    16, which must give the same bytes."""
-    import torch
-    from raytracer_amd import dist as rd
-    from raytracer_amd.synth import synthetic_scene
-    scene = synthetic_scene(scale=1.0).copy(spp=2)
-    assert (scene.width, scene.height, len(scene.spheres), len(scene.tri_verts)) == (7680, 4320, 1000000, 10000000)
-    world = 16
-    with ra.Tracer() as t:
+class TestK5FullScale:
+    """The synthetic scene at full scale (10^6 spheres + 10^7 triangles) on the full 7680x4320 film, 2 spp: rendered
+    once, compared crop by crop."""
+
+    @pytest.fixture(scope="class")
+    def k5(self):
+        from raytracer_amd.synth import synthetic_scene
+        scene = synthetic_scene(scale=1.0).copy(spp=2)
+        assert (scene.width, scene.height, len(scene.spheres), len(scene.tri_verts)) == (7680, 4320, 1000000, 10000000)
+        t = ra.Tracer()
         t.load_scene(scene)
         rgb, rgbf, st = t.render(want_float=True)
         assert st.accel_used == ra.RT_ACCEL_LBVH and st.rays_shadow > 0 and st.rays_secondary > 0
+        yield scene, t, rgb, rgbf
+        t.close()
+
+    @pytest.mark.parametrize("x0,y0,shard", [(3840, 2160, True), (3012, 1796, True), (4700, 2500, False), (2200, 2900, False),
+                                             (2800, 1500, False), (4100, 3300, False), (3600, 1300, False), (4400, 3000, False)])
+    def test_k5_full_scene_and_film_against_oracle_crops(self, oracle, k5, x0, y0, shard):
+        """The oracle tests every primitive for every ray (half a second per ray), so each case compares one 4x4
+        crop -- centre and off-centre, all on geometry; the last two hold ray trees five levels deep (843 and 2 065
+        rays for their 32 samples), the others 128 rays -- in float (eight cases, one crop each, so that a run
+        reports progress every minute); for two of them the crop's tile is also rendered as part of a shard of
+        16, which must give the same bytes."""
+        import torch
+        from raytracer_amd import dist as rd
+        scene, t, rgb, rgbf = k5
+        world = 16
         roi = (x0, y0, x0 + 4, y0 + 4)
         orgb, orgbf, cnt, _ = oracle.render(scene, roi=roi, threads=16)
         assert cnt.shadow > 0, "the crop was meant to see geometry"
