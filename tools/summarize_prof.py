@@ -112,6 +112,9 @@ def main():
             dominant = b["roofline"]["kernel"].split("<")[0]           # k_extend or k_shadow
             if dominant in entry:
                 b["roofline"]["traffic"] = entry[dominant]
+                if isinstance(b["roofline"].get("hbm"), dict):
+                    b["roofline"]["hbm"]["traffic"] = entry[dominant]
+                b["roofline"]["traffic_source"] = "the rocprofv3 PMC passes of this profile run (2 x TCC FETCH_SIZE + WRITE_SIZE per launch)"
             b["roofline"]["rocprofv3_kernel_trace"] = timed
             json.dump(b, open(prefix + "_bench.json", "w"))
     json.dump(timed, open(prefix + "_timed_launches.json", "w"), indent=1, sort_keys=True)
