@@ -373,15 +373,19 @@ __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const S
                         az = bitsf(((eb >> 16) & 0xFFu) << 23) * R.inv.z;
             const float bx = __builtin_fmaf(q0.x, R.inv.x, R.noi.x), by = __builtin_fmaf(q0.y, R.inv.y, R.noi.y),
                         bz = __builtin_fmaf(q0.z, R.inv.z, R.noi.z);
+            // The plane a ray enters a slab by depends only on the sign of its slope: the near / far byte of all four
+            // children is picked per axis with one select on the packed word, so the box tests need no min / max.
+            const bool sx = R.inv.x < 0.0f, sy = R.inv.y < 0.0f, sz = R.inv.z < 0.0f;
             const uint32_t lx = fbits(q1.x), ly = fbits(q1.y), lz = fbits(q1.z), hx = fbits(q1.w), hy = fbits(q2.x), hz = fbits(q2.y);
+            const uint32_t nx = sx ? hx : lx, fx = sx ? lx : hx, ny = sy ? hy : ly, fy = sy ? ly : hy, nz = sz ? hz : lz, fz = sz ? lz : hz;
             float kk[4]; bool hh[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                // (lo, hi) plane of an axis in one packed multiply-add
-                const v2f tx = __builtin_elementwise_fma((v2f){(float)((lx >> (8 * c)) & 0xFFu), (float)((hx >> (8 * c)) & 0xFFu)}, (v2f){ax, ax}, (v2f){bx, bx});
-                const v2f ty = __builtin_elementwise_fma((v2f){(float)((ly >> (8 * c)) & 0xFFu), (float)((hy >> (8 * c)) & 0xFFu)}, (v2f){ay, ay}, (v2f){by, by});
-                const v2f tz = __builtin_elementwise_fma((v2f){(float)((lz >> (8 * c)) & 0xFFu), (float)((hz >> (8 * c)) & 0xFFu)}, (v2f){az, az}, (v2f){bz, bz});
-                hh[c] = slab_hit<8>(tx, ty, tz, tmax, kk[c]);
+                // (near, far) plane of an axis in one packed multiply-add
+                const v2f tx = __builtin_elementwise_fma((v2f){(float)((nx >> (8 * c)) & 0xFFu), (float)((fx >> (8 * c)) & 0xFFu)}, (v2f){ax, ax}, (v2f){bx, bx});
+                const v2f ty = __builtin_elementwise_fma((v2f){(float)((ny >> (8 * c)) & 0xFFu), (float)((fy >> (8 * c)) & 0xFFu)}, (v2f){ay, ay}, (v2f){by, by});
+                const v2f tz = __builtin_elementwise_fma((v2f){(float)((nz >> (8 * c)) & 0xFFu), (float)((fz >> (8 * c)) & 0xFFu)}, (v2f){az, az}, (v2f){bz, bz});
+                hh[c] = slab_hit<0>(tx, ty, tz, tmax, kk[c]);
             }
             k0 = kk[0]; k1 = kk[1]; k2 = kk[2]; k3 = kk[3];
             h0 = hh[0]; h1 = hh[1]; h2 = hh[2]; h3 = hh[3];
