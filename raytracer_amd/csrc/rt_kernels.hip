@@ -106,6 +106,34 @@ __device__ __forceinline__ void for_each_group(uint32_t* wq, uint64_t ngroups, F
     }
 }
 
+// The same hand-out one draw at a time, for a wave that asks for its next chunk of work itself: next() gives a
+// group of the launch that nobody else gets, or false when the home queue and its neighbours are empty.  The draw
+// for the following call is issued at once, so its latency hides behind the work on the group just handed out.
+struct GroupSource {
+    uint32_t* wq;
+    uint64_t ngroups;
+    uint32_t q, lane, ticket;
+    int probes;
+    __device__ __forceinline__ void init(uint32_t* wq_, uint64_t ngroups_) {
+        wq = wq_; ngroups = ngroups_;
+        lane = threadIdx.x & 63u;
+        const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+        q = wave % RT_NQ;
+        probes = 0;
+        ticket = wq_grab(wq + q * RT_WQ_STRIDE, lane);
+    }
+    __device__ __forceinline__ bool next(uint64_t& grp) {
+        while (true) {
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+            grp = (uint64_t)k * RT_NQ + q;
+            if (grp < ngroups) { ticket = wq_grab(wq + q * RT_WQ_STRIDE, lane); return true; }
+            if (++probes > RT_WQ_PROBES) return false;
+            q = (q + 1) % RT_NQ;
+            ticket = wq_grab(wq + q * RT_WQ_STRIDE, lane);
+        }
+    }
+};
+
 // A ray of generation g whose colour is final hands it to its parent (`parent` = the parent's pool
 // index, or the sample index for g == 0; `slot` = 0 for a reflection ray, 1 for a refraction ray).
 // A parent with ONE child is finished by that very colour: local + spec (or trans) * child, the
@@ -1112,7 +1140,7 @@ __device__ __forceinline__ void extend_team(const DScene& S, const DPool& P, con
 #endif
 
 
-// Closest-hit walk with lane refill (see shadow_chunk for the idea): a wave owns `n` consecutive
+// Closest-hit walk with lane refill (see shadow_chunks for the idea): a wave owns `n` consecutive
 // rays [first, first + n) of the generation, n <= REFILL_GROUPS * 64 and first a multiple
 // of 64.  A lane whose walk has ended waits until REFILL_MIN lanes have, then those lanes
 // write their hit (or miss) records together and take the next rays of the chunk.  Rays
@@ -1154,7 +1182,7 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
             cur = lane_inner_step<WIDE>(S, cur, R, tmax, stk, ts);
             if (cur == LANE_DONE) state = FIN;
         }
-        // lanes at a leaf wait until LEAF_MIN of them are (see shadow_chunk)
+        // lanes at a leaf wait until LEAF_MIN of them are (see shadow_chunks)
         const bool at_leaf = state == WALK && !at_node;
         const unsigned long long leafm = ballot64(at_leaf);
         if (leafm != 0ull && (__popcll(leafm) >= LEAF_MIN || ballot64(at_node) == 0ull)) {
@@ -1478,14 +1506,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(DPool P, DCounters* C, int 
 // wave stays full until the chunk runs out.  One loop iteration = one node or one leaf per
 // lane, exactly the step of lbvh_trace<true>.
 template <bool WIDE>
-__device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, int* lds_stack, uint64_t first, uint64_t end, TraceStats& ts) {
+__device__ __forceinline__ void shadow_chunks(const DScene& S, const DPool& P, int* lds_stack, GroupSource& src, uint64_t span,
+                                      uint64_t items, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t nl = (uint32_t)S.nl;
-    const uint32_t count = (uint32_t)(end - first);
-    uint32_t next = 64;                  // wave-uniform: first item of the chunk not handed out yet
-    uint32_t k = lane;                   // this lane's item, relative to `first`
-    bool alive = k < count;
+    uint64_t first = 0;                  // wave-uniform: the chunk being handed out to the lanes, [first, first + count)
+    uint32_t count = 0, next = 0;        // ... and the first item of it not handed out yet
+    bool more = true;                    // wave-uniform: the launch may still have chunks for this wave
+    uint64_t item = 0;                   // this lane's item
+    bool alive = false;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
     float dmax = 0, tmax = 0;
     double dd = 1;
@@ -1493,10 +1523,10 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, in
     int cur = LANE_DONE;
     LdsStack stk;
     stk.init(lds_stack);
-    auto start = [&](uint32_t rel) {
-        const uint64_t item = first + rel;
-        uint32_t h = (uint32_t)(item / nl);
-        int j = (int)(item - (uint64_t)h * nl);
+    auto start = [&](uint64_t it) {
+        item = it;
+        uint32_t h = (uint32_t)(it / nl);
+        int j = (int)(it - (uint64_t)h * nl);
         o = f3(P.hp[P.hitlist[h]]);
         light_dir(S.lights[j], o, d, dmax);
         dd = (double)dot3(d, d);
@@ -1504,9 +1534,34 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, in
         tmax = slab_tmax(R, dmax);
         cur = 0;                                    // both trees keep their root at node 0
         stk.reset();
+        alive = true;
     };
-    if (alive) start(k);
-    while (ballot64(alive) != 0ull) {
+    while (true) {
+        // idle lanes take the next items of the chunk; a chunk that has run out is followed by the wave's next one at
+        // once, so the lanes still walking the old chunk's longest rays have company (walking every chunk to its end
+        // on its own left two thirds of the lane slots empty: a chunk's longest ray takes as long as the rest of it)
+        const unsigned long long idle = ~ballot64(alive);
+        if (more && __popcll(idle) >= REFILL_MIN) {
+            if (next >= count) {
+                uint64_t c;
+                if (src.next(c)) {
+                    first = c * span;
+                    count = (uint32_t)(first + span < items ? span : items - first);
+                    next = 0;
+                } else more = false;
+            }
+            if (more) {
+                if (!alive) {
+                    const uint32_t rel = next + (uint32_t)__popcll(idle & below);
+                    if (rel < count) start(first + rel);
+                }
+                next += (uint32_t)__popcll(idle);
+            }
+        }
+        if (ballot64(alive) == 0ull) {
+            if (!more) break;
+            continue;
+        }
         int verdict = -1;                // 0: reaches the light, 1: occluded
         const bool at_node = alive && cur >= 0;
         if (at_node) {
@@ -1539,16 +1594,8 @@ __device__ __forceinline__ void shadow_chunk(const DScene& S, const DPool& P, in
             stk.reset();
         }
         if (verdict >= 0) {
-            P.occl[first + k] = (uint8_t)verdict;
+            P.occl[item] = (uint8_t)verdict;
             alive = false;
-        }
-        const unsigned long long idle = ~ballot64(alive);
-        if (next < count && __popcll(idle) >= REFILL_MIN) {
-            if (!alive) {
-                uint32_t rel = next + (uint32_t)__popcll(idle & below);
-                if (rel < count) { k = rel; start(k); alive = true; }
-            }
-            next += (uint32_t)__popcll(idle);
         }
     }
 }
@@ -1591,10 +1638,9 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
             for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, groups,
                            [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });
         } else {
-            for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + span - 1) / span, [&](uint64_t c) {
-                const uint64_t first = c * span;
-                shadow_chunk<ACCEL == 4>(S, P, (int*)lds, first, first + span < items ? first + span : items, ts);
-            });
+            GroupSource src;
+            src.init(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, (items + span - 1) / span);
+            shadow_chunks<ACCEL == 4>(S, P, (int*)lds, src, span, items, ts);
         }
     } else if (ACCEL == 5) {
         // team walks: the wave owns TEAM_NRS consecutive items, lane r the r-th
