@@ -19,7 +19,7 @@ void rtk_extend(hipStream_t st, int accel, const DScene& S, const DPool& P, DCou
                 RtkLaunchCache& cache, bool defer_miss = false);
 // prefix sums over the wave masks of generation g: hit list, hit / next-generation counts, child offsets
 void rtk_reduce_stats(hipStream_t st, const DPool& P, DCounters* C);
-// extend_accel: the walk of the extend launch before it (5 = team walks leave flag bytes, not masks)
+// extend_accel: the walk of the extend launch before it (2, 4, 5 = per-lane and team walks leave flag bytes, not masks)
 void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t bound, int max_blocks, int extend_accel);
 void rtk_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
                 uint64_t bound, int max_blocks, bool count, RtkLaunchCache& cache);

@@ -1085,6 +1085,12 @@ __device__ __forceinline__ void extend_one(const DScene& S, const DPool& P, cons
         }
     }
     if (deliver_now) deliver_from(S, P, g, R.parent, R.slot, S.bg, ploc);
+    if (ACCEL == 2 || ACCEL == 4) {
+        // launches of per-lane walks leave a flag byte per ray (their chunk walks finish rays out of order, see
+        // extend_chunks); the scan builds the masks
+        if (inrange) P.rflag[i] = (uint8_t)((hit ? 1u : 0u) | (refl ? 2u : 0u) | (refr ? 4u : 0u));
+        return;
+    }
     unsigned long long mh = __ballot(hit), m1 = __ballot(refl), m2 = __ballot(refr);
     if ((threadIdx.x & 63) == 0 && inrange) {
         uint32_t grp = gbase + (i >> 6);
@@ -1140,19 +1146,21 @@ __device__ __forceinline__ void extend_team(const DScene& S, const DPool& P, con
 #endif
 
 
-// Closest-hit walk with lane refill (see shadow_chunks for the idea): a wave owns `n` consecutive
-// rays [first, first + n) of the generation, n <= REFILL_GROUPS * 64 and first a multiple
-// of 64.  A lane whose walk has ended waits until REFILL_MIN lanes have, then those lanes
-// write their hit (or miss) records together and take the next rays of the chunk.  Rays
-// are finished out of order, so the three ballot masks of each 64-ray group are put
-// together at the end from one flag byte per ray kept in LDS (`flags`, this wave's own).
+// Closest-hit walk with lane refill (see shadow_chunks for the idea): a wave draws chunks of `span` consecutive
+// rays of the generation (span a multiple of 64) one after the other.  A lane whose walk has ended waits until
+// REFILL_MIN lanes have, then those lanes write their hit (or miss) records together and take the next rays of the
+// chunk -- or of the wave's next chunk when this one has none left, so the longest rays of a chunk never walk alone.
+// Rays are finished out of order and a 64-ray group may be split between two refills: every ray leaves a flag
+// byte (P.rflag, as the team walks do) and the scan builds the three ballot masks of each group from the bytes.
 template <bool WIDE>
-__device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
-                                    uint32_t gbase, uint32_t first, uint32_t n, uint8_t* flags, int* lds_stack, TraceStats& ts) {
+__device__ __forceinline__ void extend_chunks(const DScene& S, const DPool& P, const GenSrc& G, int g, uint32_t start,
+                                     uint32_t count, GroupSource& src, uint32_t span, int* lds_stack, TraceStats& ts) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     enum { IDLE = 0, WALK = 1, FIN = 2 };
-    uint32_t next = 64, k = lane;
+    uint32_t first = 0, n = 0, next = 0;     // wave-uniform: the chunk being handed out, and how far
+    bool more = true;                        // wave-uniform: the launch may still have chunks for this wave
+    uint32_t i = 0;                          // this lane's ray (index inside the generation)
     int state = IDLE;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
     uint32_t parent = 0, slot = 0;
@@ -1164,8 +1172,9 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
     HitUV uv; uv.a = 0; uv.b = 0;
     LdsStack stk;
     stk.init(lds_stack);
-    auto begin = [&](uint32_t rel) {
-        RayRec rr = load_ray(P, G, g, first + rel, start + first + rel);
+    auto begin = [&](uint32_t ray) {
+        i = ray;
+        RayRec rr = load_ray(P, G, g, ray, start + ray);
         o = rr.o; d = rr.d; parent = rr.parent; slot = rr.slot; valid = rr.valid;
         best = -1; best_d2 = __builtin_inff(); uv.a = 0; uv.b = 0;
         dd = (double)dot3(d, d);
@@ -1174,9 +1183,8 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
         cur = 0; stk.reset();                       // both trees keep their root at node 0
         state = valid ? WALK : FIN;
     };
-    if (k < n) begin(k);
     while (true) {
-        if (ballot64(state != IDLE) == 0ull) break;
+        if (ballot64(state != IDLE) == 0ull && !more) break;
         const bool at_node = state == WALK && cur >= 0;
         if (at_node) {
             cur = lane_inner_step<WIDE>(S, cur, R, tmax, stk, ts);
@@ -1213,7 +1221,6 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
         const unsigned long long fin = ballot64(state == FIN);
         if (__popcll(fin) >= REFILL_MIN || ballot64(state == WALK) == 0ull) {
             if (state == FIN) {
-                const uint32_t i = first + k;
                 uint32_t bits = 0;
                 if (valid && best >= 0) {
                     F3 point, normal; int mat;
@@ -1230,29 +1237,29 @@ __device__ __forceinline__ void extend_chunk(const DScene& S, const DPool& P, co
                 } else {
                     if (valid && !(G.defer_miss && g > 0)) deliver(S, P, g, parent, slot, S.bg);
                 }
-                flags[k] = (uint8_t)bits;
+                P.rflag[i] = (uint8_t)bits;
                 state = IDLE;
             }
-            const unsigned long long idle = ballot64(state == IDLE);
-            if (next < n) {
+            // idle lanes take the chunk's next rays; what the chunk cannot serve comes from the wave's next chunk
+            for (int round = 0; round < 2 && more; round++) {
+                if (next >= n) {
+                    uint64_t c;
+                    if (!src.next(c)) { more = false; break; }
+                    first = (uint32_t)c * span;
+                    n = min(span, count - first);
+                    next = 0;
+                }
+                const unsigned long long idle = ballot64(state == IDLE);
+                if (idle == 0ull) break;
                 if (state == IDLE) {
-                    uint32_t rel = next + (uint32_t)__popcll(idle & below);
-                    if (rel < n) { k = rel; begin(k); }
+                    const uint32_t rel = next + (uint32_t)__popcll(idle & below);
+                    if (rel < n) begin(first + rel);
                 }
                 next += (uint32_t)__popcll(idle);
+                if (next <= n) break;            // every idle lane was served
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t f = (base + lane < n) ? flags[base + lane] : 0u;
-        unsigned long long mh = ballot64(f & 1u), m1 = ballot64(f & 2u), m2 = ballot64(f & 4u);
-        if (lane == 0) {
-            uint32_t grp = gbase + ((first + base) >> 6);
-            P.mask_hit[grp] = mh; P.mask_refl[grp] = m1; P.mask_refr[grp] = m2;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 template <int ACCEL, bool COUNT>
@@ -1268,7 +1275,6 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
         for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
             extend_one<ACCEL>(S, P, G, g, start, count, gbase, base + threadIdx.x, lds, ts);
     } else if (ACCEL == 2 || ACCEL == 4) {
-        __shared__ uint8_t flags[RT_BLOCK / 64][REFILL_GROUPS * 64];
         const uint64_t groups = ((uint64_t)count + 63) >> 6;
         const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
         uint64_t per = groups / (waves * 4);
@@ -1279,10 +1285,9 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
                 extend_one<ACCEL>(S, P, G, g, start, count, gbase, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
             });
         } else {
-            for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + span - 1) / span, [&](uint64_t c) {
-                const uint32_t first = (uint32_t)c * span;
-                extend_chunk<ACCEL == 4>(S, P, G, g, start, gbase, first, min(span, count - first), flags[threadIdx.x >> 6], (int*)lds, ts);
-            });
+            GroupSource src;
+            src.init(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + span - 1) / span);
+            extend_chunks<ACCEL == 4>(S, P, G, g, start, count, src, span, (int*)lds, ts);
         }
     } else if (ACCEL == 5) {
         for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, ((uint64_t)count + TEAM_NR - 1) / TEAM_NR, [&](uint64_t item) {
@@ -1542,20 +1547,22 @@ __device__ __forceinline__ void shadow_chunks(const DScene& S, const DPool& P, i
         // on its own left two thirds of the lane slots empty: a chunk's longest ray takes as long as the rest of it)
         const unsigned long long idle = ~ballot64(alive);
         if (more && __popcll(idle) >= REFILL_MIN) {
-            if (next >= count) {
-                uint64_t c;
-                if (src.next(c)) {
+            for (int round = 0; round < 2 && more; round++) {      // what the chunk cannot serve comes from the next one
+                if (next >= count) {
+                    uint64_t c;
+                    if (!src.next(c)) { more = false; break; }
                     first = c * span;
                     count = (uint32_t)(first + span < items ? span : items - first);
                     next = 0;
-                } else more = false;
-            }
-            if (more) {
+                }
+                const unsigned long long free_lanes = ~ballot64(alive);
+                if (free_lanes == 0ull) break;
                 if (!alive) {
-                    const uint32_t rel = next + (uint32_t)__popcll(idle & below);
+                    const uint32_t rel = next + (uint32_t)__popcll(free_lanes & below);
                     if (rel < count) start(first + rel);
                 }
-                next += (uint32_t)__popcll(idle);
+                next += (uint32_t)__popcll(free_lanes);
+                if (next <= count) break;            // every idle lane was served
             }
         }
         if (ballot64(alive) == 0ull) {
@@ -2070,7 +2077,7 @@ void rtk_compact(hipStream_t st, const DPool& P, DCounters* C, int g, uint64_t b
     uint64_t groups = (bound + 63) / 64;
     int blocks = (int)std::min<uint64_t>((groups + SCAN_BLOCK - 1) / SCAN_BLOCK, (uint64_t)std::min<int>(max_blocks, (int)SCAN_TILES_WANTED));
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_scan, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g, extend_accel == 5 ? 1 : 0);
+    hipLaunchKernelGGL(k_scan, dim3(blocks), dim3(SCAN_BLOCK), 0, st, P, C, g, (extend_accel == 5 || extend_accel == 2 || extend_accel == 4) ? 1 : 0);
 }
 template <bool COUNT>
 static void launch_shadow(hipStream_t st, int accel, const DScene& S, const DPool& P, DCounters* C, int g,
