@@ -1136,13 +1136,13 @@ __device__ __forceinline__ void extend_team(const DScene& S, const DPool& P, con
 }
 
 #ifndef REFILL_GROUPS
-#define REFILL_GROUPS 8
+#define REFILL_GROUPS 2
 #endif
 #ifndef REFILL_MIN
 #define REFILL_MIN 16
 #endif
 #ifndef LEAF_MIN
-#define LEAF_MIN 12
+#define LEAF_MIN 20
 #endif
 
 
@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_extend(DScene S, DPo
         uint64_t per = groups / (waves * 4);
         per = per < 1 ? 1 : (per > REFILL_GROUPS ? REFILL_GROUPS : per);
         const uint32_t span = (uint32_t)per << 6;
-        if (per == 1) {      // too little work to refill from: plain 64-ray groups
+        if (groups <= waves) {      // a group per wave at most, nothing to refill from: plain 64-ray groups
             for_each_group(P.wq + (size_t)(2 * g) * RT_WQ_LAUNCH, groups, [&](uint64_t grp) {
                 extend_one<ACCEL>(S, P, G, g, start, count, gbase, (uint32_t)(grp << 6) + (threadIdx.x & 63u), lds, ts);
             });
@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_WAVES_ATTR void k_shadow(DScene S, DPo
         uint64_t per = groups / (waves * 4);
         per = per < 1 ? 1 : (per > REFILL_GROUPS ? REFILL_GROUPS : per);
         const uint64_t span = per << 6;
-        if (per == 1) {      // too little work to refill from: plain 64-item groups
+        if (groups <= waves) {      // a group per wave at most, nothing to refill from: plain 64-item groups
             for_each_group(P.wq + (size_t)(2 * g + 1) * RT_WQ_LAUNCH, groups,
                            [&](uint64_t grp) { one((grp << 6) + (threadIdx.x & 63u)); });
         } else {
