@@ -677,7 +677,11 @@ __device__ __forceinline__ void trace(const DScene& S, float4* lds, bool active,
 #define TEAM_NR_MAX (TEAM_NR > TEAM_NRS ? TEAM_NR : TEAM_NRS)
 #define TEAM_STACK 96
 #define TEAM_REC_F4 9       // float4 per ray record (6 used; 36 words apart: the records of a wave start in different banks)
-#define TEAM_LDS_F4 (TEAM_NR_MAX * (TEAM_REC_F4 + TEAM_STACK / 4))          // per wave: records, then stacks
+#ifndef TEAM_FLUSH
+#define TEAM_FLUSH 16       // leaves waiting for their exact test before the wave stops walking to test them
+#endif
+#define TEAM_QUEUE 96       // >= TEAM_FLUSH - 1 + 64: a round adds at most one leaf per lane
+#define TEAM_LDS_F4 (TEAM_NR_MAX * (TEAM_REC_F4 + TEAM_STACK / 4) + TEAM_QUEUE / 4)   // per wave: records, stacks, leaf queue
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {            // v of the lane CTRL names (quad_perm)
@@ -703,6 +707,8 @@ __device__ __forceinline__ void team_walk(const DScene& S, float4* wave_lds, boo
     const int c = (int)(lane & 3u);
     float4* rec = wave_lds;
     int* stacks = (int*)(wave_lds + NR * TEAM_REC_F4);
+    uint32_t* queue = (uint32_t*)(wave_lds + TEAM_NR_MAX * (TEAM_REC_F4 + TEAM_STACK / 4));
+    int qn = 0;                                                       // wave-uniform: leaves in the queue
     const double dd0 = (double)dot3(d, d);
     if (lane < (uint32_t)NR) {
         const SlabRay R = slab_ray(o, d);
@@ -783,38 +789,13 @@ __device__ __forceinline__ void team_walk(const DScene& S, float4* wave_lds, boo
             if (c == 0) ts.lane_nodes += 2;
             hit = slab_hit<8>(tx, ty, tz, tmax, tn) && ref != LANE_DONE;
         }
-        // children that are leaves: the exact test now, in the lane that holds the child
+        // children that are leaves: their exact tests -- several times the arithmetic of the rest of a round, wanted by
+        // a handful of lanes per round -- wait in a queue of (ray, leaf) pairs until TEAM_FLUSH of them can run together
         const bool at_leaf = hit && ref < 0;
-        unsigned long long key = ~0ull;
-        float ca = 0, cb = 0;
-        bool found = false;
-        if (ballot64(at_leaf) != 0ull) {
-            if (at_leaf) {
-                const float4* lf = S.leaf + 3 * (size_t)(~ref);
-                const float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
-                const float4 ro = rr[0], rd = rr[1];
-                const double dd = __hiloint2double(__float_as_int(rr[3].w), __float_as_int(rr[2].w));
-                const int prim = (int)fbits(l2.y);
-                if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
-                ts.lane_prims++;
-                float d2 = 0;
-                HitUV cand;
-                if (leaf_test(f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), dd, l0, l1, l2, ro.w, d2, cand)) {
-                    found = true;
-                    key = ((unsigned long long)fbits(d2) << 32) | (uint32_t)prim;
-                    ca = cand.a; cb = cand.b;
-                }
-            }
-        }
-        const unsigned long long fm = ballot64(found);
-        if (!ANY && fm != 0ull) {
-            // candidates meet in the ray's record: smallest (distance, primitive) wins, and the winner leaves its u, v
-            if (found) atomicMin((unsigned long long*)(rec + ray * TEAM_REC_F4 + 4), key);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (found && *(volatile unsigned long long*)(rec + ray * TEAM_REC_F4 + 4) == key) {
-                float* w = (float*)(rec + ray * TEAM_REC_F4 + 4);
-                w[2] = ca; w[3] = cb;
-            }
+        {
+            const unsigned long long lm = ballot64(at_leaf);
+            if (at_leaf) queue[qn + __popcll(lm & ((1ull << lane) - 1ull))] = ((uint32_t)ray << 28) | (uint32_t)(~ref);
+            qn += __popcll(lm);
         }
         // children that are inner nodes go on their ray's stack
         const bool push = hit && ref >= 0;
@@ -840,19 +821,66 @@ __device__ __forceinline__ void team_walk(const DScene& S, float4* wave_lds, boo
             }
             const unsigned long long ov = ballot64(over);
             const bool ray_over = ((ov >> base) & wmask) != 0ull;
-            const bool ray_found = ANY && ((fm >> base) & wmask) != 0ull;      // shadowed: nothing more to find out
             int nsp = sp - npop + __popcll(tb);
-            if (ray_over || ray_found) nsp = 0;
+            if (ray_over) nsp = 0;
             const bool first = mine && e == 0 && c == 0;                       // the ray's first lane keeps its books
             if (first) {
                 float* book = (float*)(rec + ray * TEAM_REC_F4 + 5);     // (integers kept as float bit patterns: the record is read as float4)
                 book[0] = __int_as_float(nsp);
-                if (ray_found) book[1] = __int_as_float(1);
                 if (ray_over) book[2] = __int_as_float(1);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         alive = (uint32_t)ballot64(lane < (uint32_t)NR && __float_as_int(rec[(lane < (uint32_t)NR ? lane : 0u) * TEAM_REC_F4 + 5].x) > 0);
+        // the queued exact tests, a lane each: when enough wait, and before the wave runs out of nodes to walk
+        if (qn >= TEAM_FLUSH || (alive == 0u && qn > 0)) {
+            while (qn > 0) {
+                const int m = qn < 64 ? qn : 64;
+                qn -= m;
+                unsigned long long key = ~0ull;
+                float ca = 0, cb = 0;
+                bool found = false;
+                int fray = 0;
+                if ((int)lane < m) {
+                    const uint32_t en = queue[qn + lane];
+                    fray = (int)(en >> 28);
+                    const float4* rq = rec + fray * TEAM_REC_F4;
+                    if (!(ANY && __float_as_int(rq[5].y) != 0)) {          // (a shadow ray that has its answer needs no more tests)
+                        const float4* lf = S.leaf + 3 * (size_t)(en & 0x0FFFFFFFu);
+                        const float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
+                        const float4 ro = rq[0], rd = rq[1];
+                        const double dd = __hiloint2double(__float_as_int(rq[3].w), __float_as_int(rq[2].w));
+                        const int prim = (int)fbits(l2.y);
+                        if (fbits(l2.z) != 0u) ts.sph++; else ts.tri++;
+                        ts.lane_prims++;
+                        float d2 = 0;
+                        HitUV cand;
+                        if (leaf_test(f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), dd, l0, l1, l2, ro.w, d2, cand)) {
+                            found = true;
+                            key = ((unsigned long long)fbits(d2) << 32) | (uint32_t)prim;
+                            ca = cand.a; cb = cand.b;
+                        }
+                    }
+                }
+                const unsigned long long fm = ballot64(found);
+                if (fm != 0ull) {
+                    if (ANY) {
+                        // shadowed: nothing more to find out, the ray's stack is dropped
+                        if (found) { float* book = (float*)(rec + fray * TEAM_REC_F4 + 5); book[0] = __int_as_float(0); book[1] = __int_as_float(1); }
+                    } else {
+                        // candidates meet in the ray's record: smallest (distance, primitive) wins, and the winner leaves its u, v
+                        if (found) atomicMin((unsigned long long*)(rec + fray * TEAM_REC_F4 + 4), key);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (found && *(volatile unsigned long long*)(rec + fray * TEAM_REC_F4 + 4) == key) {
+                            float* w = (float*)(rec + fray * TEAM_REC_F4 + 4);
+                            w[2] = ca; w[3] = cb;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            if (ANY) alive = (uint32_t)ballot64(lane < (uint32_t)NR && __float_as_int(rec[(lane < (uint32_t)NR ? lane : 0u) * TEAM_REC_F4 + 5].x) > 0);
+        }
     }
     if (S.profile && lane == 0) { ts.walk_cycles += __builtin_readcyclecounter() - t0; ts.steps += rounds; ts.walks++; }
     best = -1; best_d2 = dmax; uv.a = 0; uv.b = 0;
