@@ -348,9 +348,12 @@ def test_every_hierarchy_renders_the_same_image(tracer, monkeypatch):
 
 @pytest.mark.parametrize("name,kw", [("dragon", dict(width=256, height=160, spp=4)),
                                      ("plant_h_smooth", dict(width=165, height=128, spp=1, max_depth=8)),
-                                     ("outdoor_spot", dict(width=200, height=120, spp=2))])
+                                     ("outdoor_spot", dict(width=200, height=120, spp=2)),
+                                     ("dragon", dict(width=1280, height=720, spp=3))])
 def test_every_walk_renders_the_same_image(tracer, monkeypatch, name, kw):
-    """Per-lane walks everywhere, team walks everywhere, packet walks everywhere, brute force: one image, bit for bit."""
+    """Per-lane walks everywhere, team walks everywhere, packet walks everywhere, brute force: one image, bit for bit.
+    The last case is large enough (2.8 M primary rays: several chunks of two 64-ray groups per wave) for the per-lane
+    walks to run with lane refill across chunk boundaries, the first generations with it, the last ones without."""
     scene = load_scene(name).copy(**kw)
     tracer.load_scene(scene)
     rgb0, f0, st0 = tracer.render(want_float=True)
