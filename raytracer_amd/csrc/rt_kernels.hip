@@ -40,7 +40,7 @@
 #define RT_LANE_WAVES 5
 #endif
 #ifndef RT_TEAM_WAVES
-#define RT_TEAM_WAVES 4
+#define RT_TEAM_WAVES 5
 #endif
 #ifndef RT_PACKET_WAVES
 #define RT_PACKET_WAVES 6
