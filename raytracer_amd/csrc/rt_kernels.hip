@@ -348,6 +348,8 @@ struct PrivateStack {      // (the array itself is a local of the caller: a stru
     int sp;
     __device__ __forceinline__ void reset() { sp = 0; }
     __device__ __forceinline__ void push(int v) { if (sp < LBVH_STACK) e[sp++] = v; }
+    __device__ __forceinline__ void push_if(int v, bool c) { if (c) push(v); }
+    __device__ __forceinline__ void settle() {}
     __device__ __forceinline__ bool empty() const { return sp <= 0; }
     __device__ __forceinline__ int pop() { return e[--sp]; }
 };
@@ -362,12 +364,20 @@ struct LdsStack {
         else over = true;
         sp++;
     }
+    // push without a branch: the store always happens -- to the row the entry would take, or to the spare row past the
+    // last one when the stack is full -- and only the depth depends on c; settle() after a step's pushes notes a
+    // stack that outgrew its rows
+    __device__ __forceinline__ void push_if(int v, bool c) {
+        col[(sp < LANE_LDS_STACK ? sp : LANE_LDS_STACK) * RT_BLOCK] = v;
+        sp += c ? 1 : 0;
+    }
+    __device__ __forceinline__ void settle() { if (sp > LANE_LDS_STACK) over = true; }
     __device__ __forceinline__ bool empty() const { return sp <= 0; }
     __device__ __forceinline__ int pop() { --sp; return col[(sp < LANE_LDS_STACK ? sp : LANE_LDS_STACK - 1) * RT_BLOCK]; }
 };
-#define LANE_STACK_F4 (LANE_LDS_STACK * RT_BLOCK / 4)        // float4 slots of LDS a block of walkers with LdsStacks needs
+#define LANE_STACK_F4 ((LANE_LDS_STACK + 1) * RT_BLOCK / 4)  // float4 slots of LDS a block of walkers with LdsStacks needs (one spare row, see push_if)
 
-template <bool WIDE, class STK>
+template <bool WIDE, bool ANY = false, class STK>
 __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const SlabRay& R, float tmax, STK& stk, TraceStats& ts) {
     // counted in 64-byte records fetched and box pairs tested: a wide node is two pairs, and one record when its
     // boxes are quantised, two when they are floats
@@ -430,12 +440,26 @@ __device__ __forceinline__ int lane_inner_step(const DScene& S, int cur, const S
         // a missed or empty slot sorts last (an empty slot's inverted box reads as an infinite slab in the min / max test)
         k0 = (h0 && r0 != LANE_DONE) ? k0 : inf; k1 = (h1 && r1 != LANE_DONE) ? k1 : inf;
         k2 = (h2 && r2 != LANE_DONE) ? k2 : inf; k3 = (h3 && r3 != LANE_DONE) ? k3 : inf;
+        if (ANY) {
+            // a shadow query ends with ANY hit: the nearest child goes first, the other hit children wait in slot
+            // order -- no sorting network (25 of a step's 150 vector instructions)
+            const float m = fminf(fminf(fminf(k0, k1), k2), k3);
+            const bool s0 = k0 == m, s1 = !s0 && k1 == m, s2 = !s0 && !s1 && k2 == m, s3 = !s0 && !s1 && !s2;
+            stk.push_if(r3, k3 < inf && !s3);
+            stk.push_if(r2, k2 < inf && !s2);
+            stk.push_if(r1, k1 < inf && !s1);
+            stk.push_if(r0, k0 < inf && !s0);
+            stk.settle();
+            if (m < inf) return s0 ? r0 : s1 ? r1 : s2 ? r2 : r3;
+            return stk.empty() ? LANE_DONE : stk.pop();
+        }
         order2(k0, r0, k1, r1); order2(k2, r2, k3, r3);      // sorting network for four
         order2(k0, r0, k2, r2); order2(k1, r1, k3, r3);
         order2(k1, r1, k2, r2);
-        if (k3 < inf) stk.push(r3);   // farthest first: the nearer ones come off first
-        if (k2 < inf) stk.push(r2);
-        if (k1 < inf) stk.push(r1);
+        stk.push_if(r3, k3 < inf);    // farthest first: the nearer ones come off first
+        stk.push_if(r2, k2 < inf);
+        stk.push_if(r1, k1 < inf);
+        stk.settle();
         if (k0 < inf) return r0;
         return stk.empty() ? LANE_DONE : stk.pop();
     }
@@ -456,7 +480,7 @@ __device__ __forceinline__ void lbvh_trace(const DScene& S, bool active, F3 o, F
     int cur = 0;                                   // both trees keep their root at node 0
     while (cur != LANE_DONE) {
         if (cur >= 0) {
-            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stk, ts);
+            cur = lane_inner_step<WIDE, ANY>(S, cur, R, tmax, stk, ts);
         } else {
             const float4* lf = S.leaf + 3 * (size_t)(~cur);
             float4 l0 = lf[0], l1 = lf[1], l2 = lf[2];
@@ -1603,7 +1627,7 @@ __device__ __forceinline__ void shadow_chunks(const DScene& S, const DPool& P, i
         int verdict = -1;                // 0: reaches the light, 1: occluded
         const bool at_node = alive && cur >= 0;
         if (at_node) {
-            cur = lane_inner_step<WIDE>(S, cur, R, tmax, stk, ts);
+            cur = lane_inner_step<WIDE, true>(S, cur, R, tmax, stk, ts);
             if (cur == LANE_DONE) verdict = 0;
         }
         // The exact primitive test is four times the cost of a node step and only a few lanes
