@@ -308,6 +308,9 @@ extern "C" int rt_create(rt_ctx** out, const rt_options* opt) {
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->max_blocks = c->num_cu * 8;
+    // test hook: a small grid makes films of a few thousand rays take the paths of large frames (several chunks per
+    // wave in the per-lane walks, tiles shared by ticket in the scan)
+    if (const char* e = getenv("RT_MAX_BLOCKS")) c->max_blocks = std::max(8, atoi(e));
     if (c->opt.stream) { c->stream = (hipStream_t)c->opt.stream; c->own_stream = false; }
     else { HIP_TRY(acquire_stream(c->device, &c->stream)); c->own_stream = true; }
     HIP_TRY(hipMalloc(&c->d_counters, sizeof(DCounters)));

@@ -81,9 +81,13 @@ __device__ __forceinline__ void for_each_group(uint32_t* wq, uint64_t ngroups, F
     // Fewer groups than waves (the thin late generations): one group per wave, no queue.  With the
     // queue a wave draws its second group before it starts the first, so half of the waves would
     // walk two groups back to back while the other half found the queues empty and left.
-    const bool one_each = ngroups <= (uint64_t)((gridDim.x * blockDim.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const bool one_each = ngroups <= (uint64_t)nwaves;
     if (one_each && wave >= ngroups) return;
-    uint32_t q = wave % RT_NQ;
+    // every queue must be some wave's home queue (a queue that is nobody's home and no neighbour's would keep its
+    // groups): a grid of fewer waves than queues uses as many queues as it has waves
+    const uint32_t nq = nwaves < RT_NQ ? nwaves : RT_NQ;
+    uint32_t q = wave % nq;
     int probes = 0;
     uint32_t k = 0;
     if (!one_each) k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
@@ -91,10 +95,10 @@ __device__ __forceinline__ void for_each_group(uint32_t* wq, uint64_t ngroups, F
         uint64_t grp = wave;
         uint32_t kn = 0;
         if (!one_each) {
-            grp = (uint64_t)k * RT_NQ + q;
+            grp = (uint64_t)k * nq + q;
             if (grp >= ngroups) {
                 if (++probes > RT_WQ_PROBES) break;
-                q = (q + 1) % RT_NQ;
+                q = (q + 1) % nq;
                 k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wq_grab(wq + q * RT_WQ_STRIDE, lane));
                 continue;
             }
@@ -112,23 +116,25 @@ __device__ __forceinline__ void for_each_group(uint32_t* wq, uint64_t ngroups, F
 struct GroupSource {
     uint32_t* wq;
     uint64_t ngroups;
-    uint32_t q, lane, ticket;
+    uint32_t q, nq, lane, ticket;
     int probes;
     __device__ __forceinline__ void init(uint32_t* wq_, uint64_t ngroups_) {
         wq = wq_; ngroups = ngroups_;
         lane = threadIdx.x & 63u;
         const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-        q = wave % RT_NQ;
+        const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+        nq = nwaves < RT_NQ ? nwaves : RT_NQ;           // (as in for_each_group: no queue without a home wave)
+        q = wave % nq;
         probes = 0;
         ticket = wq_grab(wq + q * RT_WQ_STRIDE, lane);
     }
     __device__ __forceinline__ bool next(uint64_t& grp) {
         while (true) {
             const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-            grp = (uint64_t)k * RT_NQ + q;
+            grp = (uint64_t)k * nq + q;
             if (grp < ngroups) { ticket = wq_grab(wq + q * RT_WQ_STRIDE, lane); return true; }
             if (++probes > RT_WQ_PROBES) return false;
-            q = (q + 1) % RT_NQ;
+            q = (q + 1) % nq;
             ticket = wq_grab(wq + q * RT_WQ_STRIDE, lane);
         }
     }

@@ -145,6 +145,9 @@ WALKS = {
     "lane": {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0"},
     "lane-wide": {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0", "RT_LANE_WIDE": "1"},
     "team": {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0", "RT_LANE_WIDE": "2"},
+    # a grid of 8 blocks (20 waves): films of more than 1 300 rays walk in chunks drawn one after the other, as large frames do
+    "lane-chunks": {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0", "RT_MAX_BLOCKS": "8"},
+    "lane-wide-chunks": {"RT_PACKET_GENS": "0", "RT_PACKET_SHADOW_GENS": "0", "RT_LANE_WIDE": "1", "RT_MAX_BLOCKS": "8"},
 }
 
 

@@ -13,7 +13,7 @@ from conftest import bits, same_float_image
 
 pytestmark = pytest.mark.gpu
 
-ENV_KEYS = ("RT_PACKET_GENS", "RT_PACKET_SHADOW_GENS", "RT_LANE_WIDE", "RT_TREE")
+ENV_KEYS = ("RT_PACKET_GENS", "RT_PACKET_SHADOW_GENS", "RT_LANE_WIDE", "RT_TREE", "RT_MAX_BLOCKS")
 FOUND = (79, 2989, 11138, 13308)          # seeds of earlier findings
 
 

@@ -30,7 +30,7 @@ from _oracle import Oracle  # noqa: E402
 from conftest import same_float_image  # noqa: E402
 
 SCRATCH = []
-ENV_KEYS = ("RT_PACKET_GENS", "RT_PACKET_SHADOW_GENS", "RT_LANE_WIDE", "RT_TREE")
+ENV_KEYS = ("RT_PACKET_GENS", "RT_PACKET_SHADOW_GENS", "RT_LANE_WIDE", "RT_TREE", "RT_MAX_BLOCKS")
 
 
 def render(scene, accel, env, frames=1, shards=0, **kw):
