@@ -299,3 +299,18 @@ def test_header_layout_seen_by_a_c_compiler_matches_the_ctypes_binding():
         seen[sname].add(field)
     for sname, st in structs.items():
         assert seen[sname] == {f for f, _ in st._fields_}, sname
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """Every RT_* variable the native sources read with getenv appears in INTEGRATION.md's table."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "raytracer_amd", "csrc", "*.*")):
+        if f.endswith((".hip", ".cpp", ".h", ".c")):
+            names |= set(re.findall(r'getenv\("(RT_[A-Z_0-9]+)"\)', open(f).read()))
+    assert len(names) > 10
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
